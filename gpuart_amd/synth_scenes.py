@@ -1,0 +1,121 @@
+"""Seeded synthetic scenes for tests and bench (the reference's data.zip is absent).
+
+Scenes are lists of primitive descriptions `(type, [floats])`:
+    sphere   (0): cx cy cz r
+    disc     (1): cx cy cz  nx ny nz  r
+    triangle (2): v0 v1 v2                (9 floats)
+    cone     (3): c1 (3) c2 (3) r1 r2
+fed unchanged to the product (`Renderer::SetPrimitives` through the C API) and to the oracle.
+All coordinates are float32 values, so both sides see identical inputs.
+"""
+import numpy as np
+
+SPHERE, DISC, TRIANGLE, CONE = 0, 1, 2, 3
+
+# Reference default camera / lighting (src/main.cpp:609-613,622; src/renderer.cpp:202-209)
+DEFAULT_CAMERA = dict(pos=(0.1, -3.05, 1.0), up=(0.0, 0.0, 1.0), dir=None, fov_y=60.0, screen_dist=0.2)
+# Benchmark camera: closer, so the mesh fills a large part of the frame.
+BENCH_CAMERA = dict(pos=(0.1, -1.6, 0.9), up=(0.0, 0.0, 1.0), dir=None, fov_y=60.0, screen_dist=0.2)
+SUN_AZIMUTH = np.float32(3.1415926)
+SUN_ALTITUDE = np.float32(3.1415926) / np.float32(4)
+USER_SPHERE = (-0.4, 0.0, 0.2, 0.0)
+
+
+def camera_dir(cam):
+    """Dir = (0,0,0.95) - Pos, in float32 like Vec3f (src/main.cpp:611)."""
+    p = np.array(cam["pos"], np.float32)
+    return tuple((np.array([0, 0, 0.95], np.float32) - p).tolist())
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+def box_scene():
+    """The reference's InitBox (src/scenes.cpp:49-68): 9 hard-coded primitives."""
+    T = lambda *v: (TRIANGLE, [f32(x) for x in v])
+    return [
+        (SPHERE, [0, 0, f32(0.3), f32(0.3)]),
+        (DISC, [0, 0, 0, 0, 0, 1, 6]),
+        T(1, -1, 0, 1, 1, 0, 1, 1, 1),
+        T(1, -1, 0, 1, 1, 1, 1, -1, 1),
+        (CONE, [f32(0.5), f32(-0.7), 0, f32(0.5), f32(-0.7), f32(0.35), f32(0.2), f32(0.2)]),
+        T(1, 1, 0, 1, 1, 1, -1, 1, 1),
+        T(-1, 1, 1, -1, 1, 0, 1, 1, 0),
+        T(-1, -1, 0, -1, 1, 0, -1, 1, 1),
+        T(-1, -1, 0, -1, 1, 1, -1, -1, 1),
+    ]
+
+
+def scene_p(seed=1, nspheres=256, ndiscs=16, ncones=0):
+    """Scene P, "primitives-only" (cfg1/cfg2): floor disc + spheres resting on it + tilted discs."""
+    rs = np.random.RandomState(seed)
+    prims = [(DISC, [0, 0, 0, 0, 0, 1, 6])]
+    for _ in range(nspheres):
+        x, y = rs.uniform(-2, 2, 2)
+        r = rs.uniform(0.03, 0.15)
+        prims.append((SPHERE, [f32(x), f32(y), f32(r), f32(r)]))
+    for _ in range(ndiscs):
+        x, y = rs.uniform(-2, 2, 2)
+        z = rs.uniform(0.2, 1.0)
+        r = rs.uniform(0.1, 0.3)
+        n = rs.uniform(-1, 1, 3)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        prims.append((DISC, [f32(x), f32(y), f32(z), f32(n[0]), f32(n[1]), f32(n[2]), f32(r)]))
+    for _ in range(ncones):
+        x, y = rs.uniform(-2, 2, 2)
+        h = rs.uniform(0.1, 0.5)
+        r1, r2 = rs.uniform(0.02, 0.12, 2)
+        dx, dy = rs.uniform(-0.1, 0.1, 2)
+        prims.append((CONE, [f32(x), f32(y), 0.0, f32(x + dx), f32(y + dy), f32(h), f32(r1), f32(r2)]))
+    return prims
+
+
+def dragon_class_mesh(nu=224, nv=224):
+    """Model-space vertices (float32, extent ~0.2) and faces of the dragon-class stand-in mesh:
+    an upright displaced torus, nu*nv*2 triangles (224x224 -> 100 352), meant to be loaded
+    like the reference's dragon: magnification 10, translation (0,0,-0.5) (src/scenes.cpp:35)."""
+    u = (np.arange(nu) * (2 * np.pi / nu))[:, None]
+    v = (np.arange(nv) * (2 * np.pi / nv))[None, :]
+    R = 0.5
+    r = 0.2 * (1.0 + 0.25 * np.sin(7 * u) * np.cos(5 * v) + 0.1 * np.sin(23 * v + 3 * u))
+    wx = (R + r * np.cos(v)) * np.cos(u)
+    wz = (R + r * np.cos(v)) * np.sin(u) + 0.85
+    wy = r * np.sin(v) + 0 * u
+    world = np.stack([wx, wy, wz], -1).reshape(-1, 3)
+    model = ((world - np.array([0, 0, -0.5])) / 10.0).astype(np.float32)
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    a = (i * nv + j).ravel()
+    b = (((i + 1) % nu) * nv + j).ravel()
+    c = (((i + 1) % nu) * nv + (j + 1) % nv).ravel()
+    d = (i * nv + (j + 1) % nv + 0 * i).ravel()
+    faces = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.int32)
+    return model, faces
+
+
+def load_transform(model, magnification=10.0, translation=(0.0, 0.0, -0.5)):
+    """translation + magnification * v in float32, as LoadMeshFromPLY does (src/utils.cpp:110)."""
+    t = np.array(translation, np.float32)
+    return t[None, :] + np.float32(magnification) * model.astype(np.float32)
+
+
+def scene_d(nu=224, nv=224):
+    """Scene D, "dragon-class" (cfg3/4/5): the mesh loaded as InitDragon would + floor disc r=5."""
+    model, faces = dragon_class_mesh(nu, nv)
+    w = load_transform(model)
+    tri = w[faces].reshape(-1, 9)
+    prims = [(TRIANGLE, row.tolist()) for row in tri]
+    prims.append((DISC, [0, 0, 0, 0, 0, 1, 5]))
+    return prims
+
+
+def write_ply(path, model, faces):
+    """ASCII PLY in the dialect LoadMeshFromPLY accepts (src/utils.cpp:58-134)."""
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(model), len(faces)))
+        for x, y, z in model:
+            f.write("%.9g %.9g %.9g\n" % (x, y, z))
+        for a, b, c in faces:
+            f.write("3 %d %d %d\n" % (a, b, c))

@@ -1,0 +1,424 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the reference's UNMODIFIED GLSL on Mesa llvmpipe.
+
+Container-only (needs /root/reference/shaders and oracle/_ref/libglref.so — `make -C oracle`).
+The fixtures are data: seeded inputs + the outputs the reference shaders produced for them.
+No reference source text is stored. Usage:  python tests/golden/make_golden.py [section ...]
+
+Per-function vectors come from tiny probe main()s of our own, linked against the unmodified
+reference shader objects (the reference links separately compiled objects the same way,
+src/renderer.cpp:259-359). Frames come from the reference's four programs linked from the
+same object lists as src/renderer.cpp:259-359, driven with the uniforms of
+src/renderer.cpp:372-404,534-599. Host-side inputs (compiled BVH, camera basis, Sun direction,
+RandSeed, PixelSize) come from the oracle's host restatement (the reference's C++ host files
+need the un-vendored nanogui headers and are not buildable here — DESIGN.md "Oracle").
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "glref"))
+import glref  # noqa: E402
+from gpuart_amd import synth_scenes as S  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+D_RANDOM = "float random(float x); float random(vec2 x); float random(vec3 x); float random(vec4 x);"
+D_SPHERE = "void SphereIntersection(in vec3 a, in vec3 b, in vec3 c, in float r, out float pos, out vec3 p, out vec3 n);"
+D_DISC = "void DiscIntersection(in vec3 a, in vec3 b, in vec3 c, in float r, in vec3 dn, out float pos, out vec3 p, out vec3 n);"
+D_TRI = ("void TriangleIntersection(in vec3 a, in vec3 b, in vec3 v0, in vec3 v1, in vec3 v2, out float pos, "
+         "out vec3 p, out vec3 n, out vec2 uv);")
+D_CONE = ("void ConeIntersection(in vec3 a, in vec3 b, in vec4 q0, in vec4 q1, in vec4 q2, in float w, in float cb, "
+          "in float dc, out float pos, out vec3 p, out vec3 n);")
+D_AABB = "bool IntersectsAABB(in vec3 rs, in vec3 rd, in vec3 rdiv, in samplerBuffer t, in int addr, out float pos);"
+D_BVH = "void CheckBVHIntersection(in vec3 rs, in vec3 rd, in samplerBuffer t, out float pos, out vec3 p, out vec3 n, out int ptype);"
+D_INCL = ("void CheckIntersectionInclUserSphere(in vec3 rs, in vec3 rd, in samplerBuffer t, in vec4 us, out float pos, "
+          "out vec3 p, out vec3 n, out int ptype, out bool ush);")
+D_HEMI = "vec3 GetRandomHemisphereDirection(in vec3 v, in vec3 ri);"
+D_ICONE = "vec3 GetRandomDirectionInsideCone(in vec3 v, in vec3 n, in float ha, in vec3 ri);"
+D_SKY = "vec3 GetSkyColor(in vec3 dir, in vec4 sda);"
+
+GEOM = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "common.glsl", "noise.glsl"]
+HIT_OUT = "if (pos > 0) { O0 = vec4(pos, p); O1 = vec4(n, 0); } else { O0 = vec4(pos, 0, 0, 0); O1 = vec4(0); }"
+
+
+def pad4(a, w=0.0):
+    a = np.asarray(a, np.float32)
+    if a.shape[1] == 4:
+        return a
+    return np.concatenate([a, np.full((a.shape[0], 4 - a.shape[1]), w, np.float32)], 1)
+
+
+def unit(v):
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %7.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_hash(gl):
+    rng = np.random.RandomState(11)
+    x = rng.uniform(-4, 4, (4096, 4)).astype(np.float32)
+    x[:8] = [[0, 0, 0, 0], [1, 2, 3, 4], [-0.0, 0, 0, 0], [1e-30, 1e30, -1e-30, -1e30], [0.5, 0.5, 0.5, 0.5],
+             [0.81472367, 0.135477006, 0.905791938, 0.835008562], [3, 3, 3, 3], [-1, -2, -3, -4]]
+    o, = glref.run_probe(gl, "O0 = vec4(random(i0.x), random(i0.xy), random(i0.xyz), random(i0));",
+                         ["noise.glsl"], [x], 1, decls=D_RANDOM)
+    save("hash", x=x, out=o)
+
+
+def gen_llvmpipe_math(gl):
+    """sin/cos/pow(x,16) of the GL driver itself — pins the oracle's transcendental emulation."""
+    rng = np.random.RandomState(12)
+    a = np.concatenate([rng.uniform(0, 6.2831855, 40000), rng.uniform(-8, 8, 16000), rng.uniform(-1e-3, 1e-3, 4000),
+                        np.linspace(0, 6.2831852, 5536)]).astype(np.float32)
+    w = np.concatenate([rng.uniform(0, 1, 60000), 1 - rng.uniform(0, 1e-3, 4000), np.linspace(0, 1, 1536)]).astype(np.float32)
+    x = np.zeros((65536, 4), np.float32)
+    x[:, 0] = a
+    x[:, 1] = w
+    o, = glref.run_probe_big(gl, "O0 = vec4(sin(i0.x), cos(i0.x), pow(i0.y, 16), sqrt(i0.y));", [], [x], 1)
+    save("llvmpipe_math", x=x[:, :2].copy(), out=o)
+
+
+def gen_hemisphere(gl):
+    rng = np.random.RandomState(13)
+    n = 8192
+    v = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    v[:64] = [0, 0, 1]
+    v[64:128] = [0, 0, -1]
+    v[128:160] = unit(np.array([[1e-7, 5e-7, 1.0]])).astype(np.float32)
+    ri = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    o, = glref.run_probe(gl, "O0 = vec4(GetRandomHemisphereDirection(i0.xyz, i1.xyz), 0);", ["common.glsl", "noise.glsl"],
+                         [pad4(v), pad4(ri)], 1, decls=D_HEMI)
+    save("hemisphere", v=v, ri=ri, out=o[:, :3].copy())
+    # fuzzy specular cone sampler (common.glsl:81-106): v = reflected dir (un-normalised), normal unit
+    nrm = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    vv = (unit(rng.normal(size=(n, 3)) + 1.5 * nrm) * rng.uniform(0.2, 3, (n, 1))).astype(np.float32)
+    o, = glref.run_probe(gl, "O0 = vec4(GetRandomDirectionInsideCone(i0.xyz, i1.xyz, 10 * 3.14159/180, i2.xyz), 0);",
+                         ["common.glsl", "noise.glsl"], [pad4(vv), pad4(nrm), pad4(ri)], 1, decls=D_ICONE)
+    save("inside_cone", v=vv, normal=nrm, ri=ri, out=o[:, :3].copy())
+
+
+def rays_towards(rng, n, target, spread):
+    rs = rng.uniform(-3, 3, (n, 3))
+    aim = target + rng.normal(size=(n, 3)) * spread
+    rd = (aim - rs) * rng.uniform(0.05, 2.0, (n, 1))
+    return rs.astype(np.float32), rd.astype(np.float32)
+
+
+def gen_sphere(gl):
+    rng = np.random.RandomState(14)
+    n = 8192
+    c = rng.uniform(-1, 1, (n, 3))
+    r = rng.uniform(0.05, 1.0, (n, 1))
+    rs, rd = rays_towards(rng, n, c, r * 0.8)
+    sph = np.concatenate([c, r], 1).astype(np.float32)
+    sph[:256, 3] = 0  # radius 0 = the disabled user sphere (src/main.cpp:622)
+    rs[256:512] = (sph[256:512, :3] + 0.3 * sph[256:512, 3:4] * unit(rng.normal(size=(256, 3)))).astype(np.float32)  # inside
+    o = glref.run_probe(gl, "float pos; vec3 p, n; SphereIntersection(i0.xyz, i1.xyz, i2.xyz, i2.w, pos, p, n);" + HIT_OUT,
+                        GEOM, [pad4(rs), pad4(rd), sph], 2, decls=D_SPHERE)
+    save("sphere", rs=rs, rd=rd, sph=sph, o0=o[0], o1=o[1])
+
+
+def gen_disc(gl):
+    rng = np.random.RandomState(15)
+    n = 8192
+    c = rng.uniform(-1, 1, (n, 3))
+    r = rng.uniform(0.05, 1.5, (n, 1))
+    dn = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    dn[:512] = [0, 0, 1]
+    rs, rd = rays_towards(rng, n, c, r * 0.9)
+    rd[512:640, 2] = 0  # parallel to the z=const discs? only where dn=(0,0,1): rows <512 unaffected
+    rd[:64, 2] = 0      # grazing: dot(rdir, n) == 0
+    cr = np.concatenate([c, r], 1).astype(np.float32)
+    o = glref.run_probe(gl, "float pos; vec3 p, n; DiscIntersection(i0.xyz, i1.xyz, i2.xyz, i2.w, i3.xyz, pos, p, n);" + HIT_OUT,
+                        GEOM, [pad4(rs), pad4(rd), cr, pad4(dn)], 2, decls=D_DISC)
+    save("disc", rs=rs, rd=rd, cr=cr, dn=dn, o0=o[0], o1=o[1])
+
+
+def gen_triangle(gl):
+    rng = np.random.RandomState(16)
+    n = 8192
+    v0 = rng.uniform(-1, 1, (n, 3))
+    v1 = v0 + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1, (n, 1))
+    v2 = v0 + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1, (n, 1))
+    bary = rng.dirichlet([1, 1, 1], n)
+    inside = bary[:, :1] * v0 + bary[:, 1:2] * v1 + bary[:, 2:] * v2
+    cen = (v0 + v1 + v2) / 3
+    aim = np.where(rng.uniform(size=(n, 1)) < 0.6, inside, cen + (inside - cen) * 2.5)
+    rs = rng.uniform(-3, 3, (n, 3))
+    rd = (aim - rs) * rng.uniform(0.05, 2.0, (n, 1))
+    # edge/vertex grazing: aim exactly at a vertex / edge midpoint
+    aim[:128] = v0[:128]
+    aim[128:256] = (v1[128:256] + v2[128:256]) / 2
+    rd[:256] = (aim[:256] - rs[:256])
+    # degenerate triangles
+    v2[256:288] = v1[256:288]
+    f = lambda a: a.astype(np.float32)
+    rs, rd, v0, v1, v2 = f(rs), f(rd), f(v0), f(v1), f(v2)
+    o = glref.run_probe(gl, "float pos; vec3 p, n; vec2 uv; TriangleIntersection(i0.xyz, i1.xyz, i2.xyz, i3.xyz, i4.xyz, pos, p, n, uv);"
+                        + HIT_OUT, GEOM, [pad4(rs), pad4(rd), pad4(v0), pad4(v1), pad4(v2)], 2, decls=D_TRI)
+    save("triangle", rs=rs, rd=rd, v0=v0, v1=v1, v2=v2, o0=o[0], o1=o[1])
+
+
+def cone_quads(c1, c2, r1, r2):
+    """StoreDataIntoBVH payload of cones via the oracle's host restatement (16 floats each)."""
+    descs = [(S.CONE, list(map(float, c1[i])) + list(map(float, c2[i])) + [float(r1[i]), float(r2[i])]) for i in range(len(c1))]
+    q = np.zeros((len(descs), 16), np.float32)
+    for i, d in enumerate(descs):
+        tree, _ = O.build_bvh([d])
+        assert tree.shape[0] == 3 + 1 + 4
+        q[i] = tree[4:8].ravel()
+    return q
+
+
+def gen_cone(gl):
+    rng = np.random.RandomState(17)
+    n = 4096
+    c1 = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    ax = unit(rng.normal(size=(n, 3)))
+    ln = rng.uniform(0.1, 1.5, (n, 1))
+    c2 = (c1 + ax * ln).astype(np.float32)
+    r1 = rng.uniform(0.02, 0.5, n).astype(np.float32)
+    r2 = rng.uniform(0.02, 0.5, n).astype(np.float32)
+    r2[:512] = r1[:512]          # cylinders (CosB = 0)
+    r2[512:640] = 0.0            # pointed
+    q = cone_quads(c1, c2, r1, r2)
+    mid = (c1 + c2) / 2 + ax * ln * rng.uniform(-0.6, 0.6, (n, 1))
+    rs, rd = rays_towards(rng, n, mid, np.maximum(r1, r2)[:, None] * 0.9)
+    rs[640:768] = (mid[640:768] + 0.2 * np.minimum(r1, r2)[640:768, None] * unit(rng.normal(size=(128, 3)))).astype(np.float32)
+    o = glref.run_probe(gl, "float pos; vec3 p, n; ConeIntersection(i0.xyz, i1.xyz, i2, i3, i4, i5.x, i5.y, i5.z, pos, p, n);"
+                        "if (pos < 1.0e-4) pos = -1;" + HIT_OUT,
+                        GEOM, [pad4(rs), pad4(rd), q[:, 0:4], q[:, 4:8], q[:, 8:12], q[:, 12:16]], 2, decls=D_CONE)
+    save("cone", rs=rs, rd=rd, c1=c1, c2=c2, r1=r1, r2=r2, quads=q, o0=o[0], o1=o[1])
+
+
+def gen_aabb(gl):
+    rng = np.random.RandomState(18)
+    n = 8192
+    lo = rng.uniform(-2, 2, (n, 3))
+    hi = lo + rng.uniform(0, 1.5, (n, 3)) * (rng.uniform(size=(n, 3)) > 0.1)  # some flat boxes
+    cen = (lo + hi) / 2
+    rs, rd = rays_towards(rng, n, cen, (hi - lo) * 0.7 + 0.02)
+    rs[:512] = (lo[:512] + (hi[:512] - lo[:512]) * rng.uniform(0, 1, (512, 3))).astype(np.float32)  # origin inside
+    rd[512:768, 0] = 0
+    rd[768:1024, 1] = 0
+    rd[1024:1280, 2] = 0
+    rs[1280:1408, 0] = lo[1280:1408, 0].astype(np.float32)  # origin on a face plane
+    lo, hi = lo.astype(np.float32), hi.astype(np.float32)
+    boxes = np.zeros((2 * n, 4), np.float32)
+    boxes[0::2, :3] = lo
+    boxes[1::2, :3] = hi
+    outs = []
+    chunk = 4096
+    for s in range(0, n, chunk):
+        o, = glref.run_probe(gl, "float pos; bool h = IntersectsAABB(i0.xyz, i1.xyz, 1/i1.xyz, BVH, 2*int(gl_FragCoord.x), pos);"
+                             "O0 = vec4(h ? 1.0 : 0.0, h ? pos : 0.0, 0, 0);",
+                             GEOM + ["bvh_intersection.glsl"], [pad4(rs[s:s + chunk]), pad4(rd[s:s + chunk])], 1,
+                             bvh=boxes[2 * s:2 * (s + chunk)], decls=D_AABB)
+        outs.append(o)
+    save("aabb", rs=rs, rd=rd, bmin=lo, bmax=hi, out=np.concatenate(outs)[:, :2].copy())
+
+
+def gen_sky(gl):
+    rng = np.random.RandomState(19)
+    n = 4096
+    d = (unit(rng.normal(size=(n, 3))) * rng.uniform(0.1, 3, (n, 1))).astype(np.float32)
+    d[:64, 2] = np.abs(d[:64, 2]) * 1e-3   # near horizon
+    d[64:128, :2] *= 1e-3                  # near zenith
+    for k, alt in enumerate([np.float32(3.1415926) / np.float32(4), np.float32(0.1), np.float32(1.5)]):
+        sun = O.sun_direction(S.SUN_AZIMUTH, alt)
+        sda = [float(sun[0]), float(sun[1]), float(sun[2]), float(alt)]
+        o, = glref.run_probe(gl, "O0 = vec4(GetSkyColor(i0.xyz, i1), 0);", ["sky.glsl"],
+                             [pad4(d), np.tile(np.array(sda, np.float32), (n, 1))], 1, decls=D_SKY)
+        save("sky_%d" % k, dir=d, sun_dir_alt=np.array(sda, np.float32), out=o[:, :3].copy())
+
+
+# ---- scenes / frames ---------------------------------------------------------------------------
+class RefPrograms:
+    """The reference's four programs, linked from the object lists of src/renderer.cpp:259-359."""
+
+    def __init__(self, gl, max_segments=None):
+        self.gl = gl
+        geo = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "intersection.glsl", "sky.glsl",
+               "bvh_intersection.glsl"]
+        r = gl.ref_shader
+        self.cam = gl.program([r("cam_init.glsl"), r("vertex.glsl")])
+        self.direct = gl.program([r(x) for x in geo] + [r("direct_lighting.glsl"), r("common.glsl"), r("vertex.glsl")])
+        edit = None
+        if max_segments is not None and max_segments != 5:
+            edit = ("const int MAX_PATH_SEGMENTS = 5;", "const int MAX_PATH_SEGMENTS = %d;" % max_segments)
+        self.pt = gl.program([r(x) for x in geo] + [r("path_tracing.glsl", edit=edit), r("common.glsl"), r("noise.glsl"),
+                                                    r("vertex.glsl")])
+        self.norm = gl.program([r("pt_normalize.glsl"), r("vertex.glsl")])
+
+
+class RefRenderer:
+    """Drives the reference programs the way src/renderer.cpp does (uniform for uniform)."""
+
+    def __init__(self, gl, progs, W, H, cam, tree):
+        self.gl, self.p, self.W, self.H = gl, progs, W, H
+        self.camd = cam
+        self.cam = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+        self.tbo = gl.tbo(tree)
+        self.rstart, self.rdir = gl.tex(W, H), gl.tex(W, H)
+        fb = gl.fbo([self.rstart, self.rdir])
+        c = self.cam
+        gl.set_uniforms(progs.cam, Pos=c[0:3], BottomLeft=c[3:6], DeltaHorz=c[6:9], DeltaVert=c[9:12])
+        gl.draw(progs.cam, fb, W, H)
+        self.acc = [gl.tex(W, H), gl.tex(W, H)]
+        self.accfb = [gl.fbo([t]) for t in self.acc]
+        self.out = gl.tex(W, H)
+        self.outfb = gl.fbo([self.out])
+        self.sun_az, self.sun_alt, self.sun_on = S.SUN_AZIMUTH, S.SUN_ALTITUDE, 1
+        self.us, self.us_em, self.us_flags = S.USER_SPHERE, 0.0, 0
+        self.seeds = None
+        self.reset()
+
+    def reset(self):
+        self.sel, self.n = 0, 0
+        self.gl.L.glref_clear_fbo(self.accfb[0], 0, 0, 0, 1)
+        self.seed_idx = 0
+
+    def _common(self, prog):
+        gl = self.gl
+        sun = O.sun_direction(self.sun_az, self.sun_alt)
+        gl.bind(0, self.rdir); gl.bind(1, self.rstart); gl.bind(2, self.tbo[0], buffer_tex=True)
+        gl.set_uniforms(prog, RDir=0, RStart=1, BVH=2, SunDirAlt=[sun[0], sun[1], sun[2], self.sun_alt],
+                        SunDirectLightingEnabled=int(self.sun_on), UserSphere=list(self.us),
+                        UserSphereFlags=("u", self.us_flags))
+
+    def cam_rays(self):
+        return self.gl.read(self.rstart, self.W, self.H), self.gl.read(self.rdir, self.W, self.H)
+
+    def direct(self):
+        self._common(self.p.direct)
+        self.gl.draw(self.p.direct, self.outfb, self.W, self.H)
+        self.gl.finish()
+        return self.gl.read(self.out, self.W, self.H)
+
+    def pt_pass(self, npaths, rand_seed):
+        gl = self.gl
+        src, dst = self.sel, self.sel ^ 1
+        self._common(self.p.pt)
+        gl.bind(3, self.acc[src])
+        gl.set_uniforms(self.p.pt, PrevRadiance=3, NumPathsPerPixel=int(npaths), PixelSize=float(self.cam[12]),
+                        CameraPos=self.cam[0:3], UserSphereEm=[self.us_em] * 3, RandSeed=[float(x) for x in rand_seed])
+        gl.draw(self.p.pt, self.accfb[dst], self.W, self.H)
+        gl.finish()
+        self.n += npaths
+        self.sel ^= 1
+        self.last = dst
+        return gl.read(self.acc[dst], self.W, self.H)
+
+
+def scene_tree(name):
+    prims = {"box": S.box_scene, "scene_p": S.scene_p, "scene_d": S.scene_d,
+             "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64)}[name]()
+    tree, depth = O.build_bvh(prims)
+    return prims, tree, depth
+
+
+def default_cam(which=S.DEFAULT_CAMERA):
+    c = dict(which)
+    c["dir"] = S.camera_dir(c)
+    return c
+
+
+def gen_camrays(gl):
+    progs = RefPrograms(gl)
+    _, tree, _ = scene_tree("box")
+    for W, H in [(64, 36), (37, 23)]:
+        r = RefRenderer(gl, progs, W, H, default_cam(), tree)
+        rs, rd = r.cam_rays()
+        save("camrays_%dx%d" % (W, H), cam=r.cam, rstart=rs[..., :3].copy(), rdir=rd[..., :3].copy())
+
+
+def gen_traverse(gl):
+    progs = RefPrograms(gl)
+    rng = np.random.RandomState(21)
+    for name, (W, H), camsel in [("box", (96, 96), S.DEFAULT_CAMERA), ("scene_pc", (96, 54), S.DEFAULT_CAMERA),
+                                 ("scene_d", (128, 72), S.BENCH_CAMERA)]:
+        _, tree, _ = scene_tree(name)
+        r = RefRenderer(gl, progs, W, H, default_cam(camsel), tree)
+        rs, rd = r.cam_rays()
+        rs, rd = rs.reshape(-1, 4), rd.reshape(-1, 4)
+        body = ("float pos; vec3 p, n; int t; bool ush; CheckIntersectionInclUserSphere(i0.xyz, i1.xyz, BVH, vec4(-0.4, 0, 0.2, 0), pos, p, n, t, ush);"
+                "if (t >= 0) { O0 = vec4(pos, p); O1 = vec4(n, float(t) + (ush ? 0.5 : 0.0)); } else { O0 = vec4(-1, 0, 0, 0); O1 = vec4(0, 0, 0, -1); }")
+        objs = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "common.glsl", "noise.glsl",
+                "bvh_intersection.glsl", "intersection.glsl"]
+        o0, o1 = glref.run_probe_big(gl, body, objs, [rs, rd], 2, bvh=tree, decls=D_INCL, chunk=4096)
+        # secondary rays: from the primary hit points, random directions (incoherent) + sun direction
+        hit = o1[:, 3] >= 0
+        n2 = min(4096, int(hit.sum()))
+        idx = np.flatnonzero(hit)[rng.permutation(int(hit.sum()))[:n2]]
+        rs2 = np.zeros((n2, 4), np.float32); rs2[:, :3] = o0[idx, 1:4]
+        rd2 = np.zeros((n2, 4), np.float32)
+        d = unit(rng.normal(size=(n2, 3))); d *= np.sign((d * o1[idx, :3]).sum(1, keepdims=True)); rd2[:, :3] = d
+        sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+        rd2[n2 // 2:, :3] = sun
+        s0, s1 = glref.run_probe_big(gl, body, objs, [rs2, rd2], 2, bvh=tree, decls=D_INCL, chunk=4096)
+        save("traverse_" + name, scene=name, W=W, H=H, cam=r.cam, rs=rs[:, :3].copy(), rd=rd[:, :3].copy(), o0=o0, o1=o1,
+             rs2=rs2[:, :3].copy(), rd2=rd2[:, :3].copy(), s0=s0, s1=s1)
+
+
+def gen_frames(gl):
+    seeds = O.randseeds(16)
+    for name, (W, H), camsel, segs in [("box", (128, 128), S.DEFAULT_CAMERA, [5, 1, 4, 8]),
+                                       ("scene_pc", (128, 72), S.DEFAULT_CAMERA, [5]),
+                                       ("scene_d", (128, 72), S.BENCH_CAMERA, [5, 8])]:
+        _, tree, _ = scene_tree(name)
+        for ms in segs:
+            progs = RefPrograms(gl, ms)
+            r = RefRenderer(gl, progs, W, H, default_cam(camsel), tree)
+            out = {}
+            if ms == 5:
+                out["direct"] = r.direct()[..., :3].copy()
+                r.sun_on = 0
+                out["direct_nosun"] = r.direct()[..., :3].copy()
+                r.sun_on = 1
+            r.reset()
+            npass = 8 if name == "box" and ms == 5 else 2
+            for k in range(npass):
+                acc = r.pt_pass(1, seeds[k])
+                if k == 0:
+                    out["pt_pass1"] = acc[..., :3].copy()
+            out["pt_acc"] = acc[..., :3].copy()
+            # a 3-paths-per-pass run (NumPathsPerPixel loop, path_tracing.glsl:154)
+            if ms == 5:
+                r.reset()
+                out["pt_3paths"] = r.pt_pass(3, seeds[0])[..., :3].copy()
+            save("frames_%s_seg%d" % (name, ms), scene=name, W=W, H=H, cam=r.cam, max_segments=ms, npasses=npass,
+                 seeds=seeds, **out)
+    # user sphere variants on the Box scene (emissive / specular / fuzzy), r = 0.25
+    _, tree, _ = scene_tree("box")
+    progs = RefPrograms(gl)
+    for tag, flags, em in [("em", 1, 2.0), ("spec", 2, 0.0), ("fuzzy", 6, 0.0), ("diffuse", 0, 0.0)]:
+        r = RefRenderer(gl, progs, 96, 96, default_cam(), tree)
+        r.us, r.us_em, r.us_flags = (-0.4, 0.0, 0.25, 0.25), em, flags
+        out = {"direct": r.direct()[..., :3].copy()}
+        r.reset()
+        out["pt_pass1"] = r.pt_pass(1, seeds[0])[..., :3].copy()
+        out["pt_acc"] = r.pt_pass(1, seeds[1])[..., :3].copy()
+        save("frames_box_usph_" + tag, scene="box", W=96, H=96, cam=r.cam, user_sphere=np.array(r.us, np.float32),
+             user_sphere_em=em, user_sphere_flags=flags, seeds=seeds, **out)
+
+
+SECTIONS = dict(hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, camrays=gen_camrays,
+                traverse=gen_traverse, frames=gen_frames)
+
+if __name__ == "__main__":
+    if not glref.available():
+        sys.exit("needs /root/reference/shaders and oracle/_ref/libglref.so (make -C oracle)")
+    gl = glref.GLRef()
+    print("GL_RENDERER =", gl.renderer())
+    for s in (sys.argv[1:] or list(SECTIONS)):
+        SECTIONS[s](gl)
