@@ -160,6 +160,13 @@ def cam_rays(cam, W, H):
     return rs, rd
 
 
+def pixel_uv(xy, W, H):
+    xy = np.ascontiguousarray(xy, np.int32)
+    out = np.zeros((xy.shape[0], 2), np.float32)
+    lib().orc_pixel_uv(_p(xy), C.c_int(xy.shape[0]), W, H, _p(out))
+    return out
+
+
 def make_params(sun_dir, sun_alt, sun_enabled=True, user_sphere=(0, 0, 0, 0), user_sphere_em=0.0, user_sphere_flags=0,
                 pixel_size=0.0, camera_pos=(0, 0, 0), max_segments=5, min_weight=0.01):
     P = Params()

@@ -164,6 +164,13 @@ void orc_cam_rays(const float *cam, int W, int H, float *rstart, float *rdir) {
         }
 }
 
+/// UV of selected pixels: xy = n x (int x, int y); out = n x 2 floats.
+void orc_pixel_uv(const int *xy, int n, int W, int H, float *out) {
+    float coef[12];
+    QuadUVCoefs(W, H, coef);
+    for (int i = 0; i < n; i++) PixelUV(xy[2 * i], xy[2 * i + 1], W, H, coef, out[2 * i], out[2 * i + 1]);
+}
+
 static void merge_stats(orc_stats *dst, const std::vector<TravStats> &ts, const std::vector<uint64_t> &segs) {
     if (!dst) return;
     memset(dst, 0, sizeof *dst);

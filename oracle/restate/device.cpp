@@ -346,10 +346,50 @@ V3 GetSkyColor(V3 dir, const float sda[4]) {
     return V3{cz.x * (1.0f - pw) + pw, mixf(cz.y, ch.y, pw), mixf(cz.z, ch.z, pw)};
 }
 
-// ---- cam_init.glsl:45-50 + vertex.glsl:29-37 ---------------------------------------------
+// ---- vertex.glsl:29-37 + GL::Utils::DrawFullscreenQuad (src/gl_utils.cpp:225-254) ------------
+// The interpolated UV of a fragment is NOT exactly ((x+.5)/W, (y+.5)/H) on llvmpipe unless W, H are
+// powers of two. It is the plane equation llvmpipe's triangle setup builds for each of the two fan
+// triangles, evaluated with two fused multiply-adds per channel (verified bit-for-bit on sizes
+// from 1x1 to 3840x2160 by tests/golden/make_golden.py `uv`):
+//   quad corners V0=(0,0) uv(0,0), V1=(W,0) uv(1,0), V2=(W,H) uv(1,1), V3=(0,H) uv(0,1);
+//   triangle A is set up in vertex order (V1,V0,V2), triangle B in order (V2,V0,V3);
+//   a pixel centre on or below the V0-V2 diagonal belongs to A.
+static void PlaneCoef(float x0, float y0, float x1, float y1, float x2, float y2, float a0, float a1, float a2,
+                      float c[3]) {
+    float x0c = x0 - 0.5f, y0c = y0 - 0.5f;
+    float dx01 = x0 - x1, dy01 = y0 - y1, dx20 = x2 - x0, dy20 = y2 - y0;
+    float e = dx01 * dy20, f = dy01 * dx20;
+    float ooa = 1.0f / (e - f);
+    float dy20o = dy20 * ooa, dy01o = dy01 * ooa, dx20o = dx20 * ooa, dx01o = dx01 * ooa;
+    float da01 = a0 - a1, da20 = a2 - a0;
+    float dadx = da01 * dy20o - da20 * dy01o;
+    float dady = da20 * dx01o - da01 * dx20o;
+    c[0] = a0 - (dadx * x0c + dady * y0c);
+    c[1] = dadx;
+    c[2] = dady;
+}
+
+void QuadUVCoefs(int W, int H, float coef[12]) {
+    float w = (float)W, h = (float)H;
+    PlaneCoef(w, 0, 0, 0, w, h, 1, 0, 1, coef + 0);   // A.u  (V1,V0,V2)
+    PlaneCoef(w, 0, 0, 0, w, h, 0, 0, 1, coef + 3);   // A.v
+    PlaneCoef(w, h, 0, 0, 0, h, 1, 0, 0, coef + 6);   // B.u  (V2,V0,V3)
+    PlaneCoef(w, h, 0, 0, 0, h, 1, 0, 1, coef + 9);   // B.v
+}
+
+void PixelUV(int x, int y, int W, int H, const float coef[12], float &u, float &v) {
+    const float *c = ((long long)(2 * y + 1) * W - (long long)(2 * x + 1) * H <= 0) ? coef : coef + 6;
+    float X = (float)x, Y = (float)y;
+    u = fmaf(c[2], Y, fmaf(c[1], X, c[0]));
+    v = fmaf(c[5], Y, fmaf(c[4], X, c[3]));
+}
+
+// ---- cam_init.glsl:45-50 -------------------------------------------------------------------
 void CamInitPixel(int x, int y, int W, int H, const float pos[3], const float bl[3], const float dh[3],
                   const float dv[3], V3 &rstart, V3 &rdir) {
-    float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+    float coef[12], u, v;
+    QuadUVCoefs(W, H, coef);
+    PixelUV(x, y, W, H, coef, u, v);
     V3 start{(bl[0] + dh[0] * u) + dv[0] * v, (bl[1] + dh[1] * u) + dv[1] * v, (bl[2] + dh[2] * u) + dv[2] * v};
     rstart = start;
     rdir = normalize3(start - V3{pos[0], pos[1], pos[2]});
@@ -397,7 +437,7 @@ V3 DirectLightingPixel(V3 rstart, V3 rdir, const float *tree, const Params &P, T
                     CheckBVHIntersection(h.p, dn, tree, sh, st);
                     if (sh.ptype == -1 || sh.pos > dist) {
                         V3 l = Lambert(dn, h.n, diffuse, 1);
-                        float d2 = dist * dist;
+                        float d2 = dot3(dts, dts);  // NIR folds sqrt(a)*sqrt(a) -> |a| (verified on goldens)
                         out = out + V3{l.x / d2, l.y / d2, l.z / d2};
                     }
                 }

@@ -85,7 +85,11 @@ void CheckIntersectionInclUserSphere(V3 rs, V3 rd, const float *tree, const floa
 // sky.glsl:34-60
 V3 GetSkyColor(V3 dir, const float sunDirAlt[4]);
 
-// cam_init.glsl:45-50 with UV from vertex.glsl:29-37 ((x+.5)/W, (y+.5)/H), row 0 = bottom.
+// vertex.glsl:29-37 as rasterised by llvmpipe: plane-equation coefficients of the two fan triangles
+// (coef = A.u, A.v, B.u, B.v; 3 floats each) and the per-pixel UV. Row 0 = bottom.
+void QuadUVCoefs(int W, int H, float coef[12]);
+void PixelUV(int x, int y, int W, int H, const float coef[12], float &u, float &v);
+// cam_init.glsl:45-50
 void CamInitPixel(int x, int y, int W, int H, const float pos[3], const float bl[3], const float dh[3],
                   const float dv[3], V3 &rstart, V3 &rdir);
 // direct_lighting.glsl:134-207

@@ -77,10 +77,10 @@ def gen_hash(gl):
 def gen_llvmpipe_math(gl):
     """sin/cos/pow(x,16) of the GL driver itself — pins the oracle's transcendental emulation."""
     rng = np.random.RandomState(12)
-    a = np.concatenate([rng.uniform(0, 6.2831855, 40000), rng.uniform(-8, 8, 16000), rng.uniform(-1e-3, 1e-3, 4000),
-                        np.linspace(0, 6.2831852, 5536)]).astype(np.float32)
-    w = np.concatenate([rng.uniform(0, 1, 60000), 1 - rng.uniform(0, 1e-3, 4000), np.linspace(0, 1, 1536)]).astype(np.float32)
-    x = np.zeros((65536, 4), np.float32)
+    a = np.concatenate([rng.uniform(0, 6.2831855, 10000), rng.uniform(-8, 8, 4000), rng.uniform(-1e-3, 1e-3, 1000),
+                        np.linspace(0, 6.2831852, 1384)]).astype(np.float32)
+    w = np.concatenate([rng.uniform(0, 1, 14000), 1 - rng.uniform(0, 1e-3, 1000), np.linspace(0, 1, 1384)]).astype(np.float32)
+    x = np.zeros((16384, 4), np.float32)
     x[:, 0] = a
     x[:, 1] = w
     o, = glref.run_probe_big(gl, "O0 = vec4(sin(i0.x), cos(i0.x), pow(i0.y, 16), sqrt(i0.y));", [], [x], 1)
@@ -89,7 +89,7 @@ def gen_llvmpipe_math(gl):
 
 def gen_hemisphere(gl):
     rng = np.random.RandomState(13)
-    n = 8192
+    n = 4096
     v = unit(rng.normal(size=(n, 3))).astype(np.float32)
     v[:64] = [0, 0, 1]
     v[64:128] = [0, 0, -1]
@@ -115,7 +115,7 @@ def rays_towards(rng, n, target, spread):
 
 def gen_sphere(gl):
     rng = np.random.RandomState(14)
-    n = 8192
+    n = 4096
     c = rng.uniform(-1, 1, (n, 3))
     r = rng.uniform(0.05, 1.0, (n, 1))
     rs, rd = rays_towards(rng, n, c, r * 0.8)
@@ -129,7 +129,7 @@ def gen_sphere(gl):
 
 def gen_disc(gl):
     rng = np.random.RandomState(15)
-    n = 8192
+    n = 4096
     c = rng.uniform(-1, 1, (n, 3))
     r = rng.uniform(0.05, 1.5, (n, 1))
     dn = unit(rng.normal(size=(n, 3))).astype(np.float32)
@@ -145,7 +145,7 @@ def gen_disc(gl):
 
 def gen_triangle(gl):
     rng = np.random.RandomState(16)
-    n = 8192
+    n = 4096
     v0 = rng.uniform(-1, 1, (n, 3))
     v1 = v0 + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1, (n, 1))
     v2 = v0 + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1, (n, 1))
@@ -202,7 +202,7 @@ def gen_cone(gl):
 
 def gen_aabb(gl):
     rng = np.random.RandomState(18)
-    n = 8192
+    n = 4096
     lo = rng.uniform(-2, 2, (n, 3))
     hi = lo + rng.uniform(0, 1.5, (n, 3)) * (rng.uniform(size=(n, 3)) > 0.1)  # some flat boxes
     cen = (lo + hi) / 2
@@ -239,6 +239,36 @@ def gen_sky(gl):
         o, = glref.run_probe(gl, "O0 = vec4(GetSkyColor(i0.xyz, i1), 0);", ["sky.glsl"],
                              [pad4(d), np.tile(np.array(sda, np.float32), (n, 1))], 1, decls=D_SKY)
         save("sky_%d" % k, dir=d, sun_dir_alt=np.array(sda, np.float32), out=o[:, :3].copy())
+
+
+def gen_uv(gl):
+    """Interpolated UV of the full-screen quad (vertex.glsl:29-37) as llvmpipe rasterises it."""
+    fs = gl.shader_src(glref.GL_FRAGMENT_SHADER, "#version 330 core\nin vec2 UV; layout(location=0) out vec4 O0;"
+                       "void main(){ O0 = vec4(UV, gl_FragCoord.xy); }")
+    prog = gl.program([gl.ref_shader("vertex.glsl"), fs])
+    rng = np.random.RandomState(20)
+    out = {}
+    for W, H in [(1, 1), (2, 3), (7, 5), (37, 23), (64, 36), (96, 96), (100, 100), (128, 72), (640, 480),
+                 (1920, 1080), (3840, 2160), (7680, 4320)]:
+        t = gl.tex(W, H)
+        fb = gl.fbo([t])
+        gl.draw(prog, fb, W, H)
+        gl.finish()
+        o = gl.read(t, W, H)
+        gl.L.glref_delete_fbo(fb)
+        gl.L.glref_delete_tex(t)
+        assert (o[:, :, 2] == np.arange(W)[None, :] + 0.5).all() and (o[:, :, 3] == np.arange(H)[:, None] + 0.5).all()
+        if W * H <= 10000:
+            out["full_%dx%d" % (W, H)] = o[:, :, :2].copy()
+        else:
+            n = 4096
+            xs = rng.randint(0, W, n); ys = rng.randint(0, H, n)
+            d = np.arange(min(W, H))  # pixels hugging the diagonal
+            xs[:1024] = (d[:: max(1, len(d) // 1024)][:1024] * W // min(W, H))[:1024] if len(d) >= 1024 else xs[:1024]
+            ys[:1024] = np.clip((xs[:1024] * H) // W + rng.randint(-1, 2, 1024), 0, H - 1)
+            out["xy_%dx%d" % (W, H)] = np.stack([xs, ys], 1).astype(np.int32)
+            out["uv_%dx%d" % (W, H)] = o[ys, xs, :2].copy()
+    save("uv", **out)
 
 
 # ---- scenes / frames ---------------------------------------------------------------------------
@@ -412,7 +442,7 @@ def gen_frames(gl):
 
 
 SECTIONS = dict(hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames)
 
 if __name__ == "__main__":
