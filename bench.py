@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path measured as BASELINE.json asks: Mrays/s (+ ms/frame) of progressive path
+tracing, dragon-class scene (Scene D: 100 352-triangle mesh + floor disc), 1920x1080, path depth 8,
+1 path per pixel per pass, on N GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run)
+
+A "step" is one progressive pass (gpuart::Renderer::RenderPathTracingPass) over the whole frame. With
+N>1 the FIXED 1080p frame is sharded by screen-space bands across ranks (strong scaling, north_star's
+"tile scaling"); after the K timed passes every rank exports its accumulated radiance and rank 0
+gathers it over RCCL (inside the timed region).
+
+Rays are counted exactly (closest-hit queries as the reference performs them: camera, bounce and Sun
+shadow rays) by running the same K passes once, untimed, in the library's reference-work mode; the
+timed run uses the default fast mode, whose images are bit-identical (tests/test_gpu_parity.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gpuart_amd import binding as B  # noqa: E402
+from gpuart_amd import synth_scenes as S  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+W, H = 1920, 1080
+MAX_SEGMENTS = 8
+
+
+def band_tile(rank, world, height):
+    """Contiguous row band of rank `rank` (heights differ by at most 8 rows; multiples of 8)."""
+    rows8 = (height + 7) // 8
+    lo = (rows8 * rank) // world * 8
+    hi = min(height, (rows8 * (rank + 1)) // world * 8) if rank < world - 1 else height
+    return lo, hi - lo
+
+
+def balanced_bands(world, height, cost_rows):
+    """Splits rows into `world` contiguous bands of roughly equal COST (cost_rows = per-row cost estimate
+    from a cheap probe pass), so that sky rows and mesh rows are balanced across ranks."""
+    c = np.cumsum(np.asarray(cost_rows, np.float64))
+    total = c[-1]
+    cuts = [0]
+    for r in range(1, world):
+        y = int(np.searchsorted(c, total * r / world))
+        y = max(cuts[-1] + 8, min(height - 8 * (world - r), (y + 4) // 8 * 8))
+        cuts.append(y)
+    cuts.append(height)
+    return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(world)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- scene + renderer (gpuart::Renderer API; scene build is not part of the timed region) ----
+    cam = dict(S.BENCH_CAMERA)
+    cam["dir"] = S.camera_dir(cam)
+    t0 = time.time()
+    prims = B.make_prims(S.scene_d())
+    r = B.Renderer(W, H, cam, device=local_rank)
+    r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+    r.set_primitives(prims)
+    r.set_max_path_segments(MAX_SEGMENTS)
+    setup_s = time.time() - t0
+    be = r.backend
+    info = be.scene_info()
+
+    # ---- tile of this rank: contiguous bands balanced by a cheap cost probe (direct lighting) ----
+    if world > 1:
+        # every rank renders the probe identically (deterministic), so no communication is needed
+        r.render_direct()
+        probe = r.read_direct()[..., :3]
+        # cost proxy: pixels that hit geometry cost ~10x sky pixels
+        sky = np.abs(probe - probe[-1:, :, :]).sum(-1) < 1e-3
+        cost_rows = np.where(sky, 1.0, 10.0).sum(1)
+        bands = balanced_bands(world, H, cost_rows)
+        y0, th = bands[rank]
+        assert r.set_tile(0, y0, W, th)
+    else:
+        bands = [(0, H)]
+        y0, th = 0, H
+
+    K, Wm = args.steps, args.warmup
+
+    def run_passes(n):
+        r.restart_path_tracing(1, n)
+        for _ in range(n):
+            r.path_tracing_pass()
+
+    # ---- exact ray / algorithmic-byte counts: the same K passes, untimed, reference-work mode ----
+    r.set_seed(5489)
+    be.set_mode(True)
+    be.counters(reset=True)
+    run_passes(K)
+    be.finish()
+    cnt = be.counters(reset=True)
+    be.set_mode(False)
+    counts = torch.tensor([cnt.rays, cnt.nodes, cnt.prim_tests[0], cnt.prim_tests[1], cnt.prim_tests[2], cnt.prim_tests[3],
+                           cnt.segments, cnt.algorithmic_bytes() + 32 * W * th * K], dtype=torch.float64, device=dev)
+    my_alg_bytes = float(counts[7])
+    if dist is not None:
+        dist.all_reduce(counts)
+    rays, nodes, segments, alg_bytes = float(counts[0]), float(counts[1]), float(counts[6]), float(counts[7])
+
+    # ---- warm-up (untimed), then EXACTLY K timed passes ----
+    r.set_seed(5489)
+    gather_buf = torch.empty((th, W, 4), dtype=torch.float32, device=dev)
+    full = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if (dist is not None and rank == 0) else None
+    run_passes(Wm)
+    be.finish()
+    r.set_seed(5489)
+    be.kernel_time(reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_passes(K)
+    if dist is not None:
+        # RCCL gather of the normalised radiance tiles to rank 0 (bands differ in height -> send/recv)
+        be.export(1, gather_buf.data_ptr(), float(K))
+        be.finish()
+        if rank == 0:
+            full[y0:y0 + th].copy_(gather_buf)
+            reqs = [dist.irecv(full[b0:b0 + bh], src=s) for s, (b0, bh) in enumerate(bands) if s != 0]
+            for q in reqs:
+                q.wait()
+        else:
+            dist.isend(gather_buf, dst=0).wait()
+    be.finish()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = be.kernel_time(reset=True)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    mrays = rays / elapsed / 1e6
+    avg_kernel_ms = kernel_ms / max(1, launches)
+    achieved_gbs = (my_alg_bytes / K) / (avg_kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample, rank 0, N=1 only ----
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        otree, _ = O.build_bvh(S.scene_d())
+        c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+        sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+        P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], MAX_SEGMENTS, 0.01)
+        acc = np.zeros((H, W, 4), np.float32)
+        t1 = time.perf_counter()
+        st = O.pt_pass(otree, c, W, H, P, O.randseeds(1)[0], 1, acc, nthreads=cores)
+        dt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                        "sample": "1 full pass of the same workload (1920x1080 Scene D, depth 8, seed pass 0): "
+                                  "%d rays in %.2f s; strict-fp32 CPU restatement, %d threads" % (st.rays, dt, cores),
+                        "ms_per_frame": round(dt * 1e3, 1)}
+
+    out = {
+        "metric": "Mrays/s (closest-hit BVH queries: camera + bounce + Sun shadow rays), path tracing, 1 path/pixel/pass",
+        "value": round(mrays, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": round(elapsed / K * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg3: Scene D (dragon-class, 100352 triangles + floor disc), 1920x1080, path tracing "
+                               "depth 8 (MAX_PATH_SEGMENTS=8, MIN_WEIGHT=0.01), 1 path/pixel/pass, Sun direct lighting on, "
+                               "benchmark camera",
+                   "frame": [W, H], "parallelism": "screen-space bands x%d" % world,
+                   "bvh_nodes": info["nodes"], "bvh_primitives": info["prims"], "bvh_depth": info["max_depth"],
+                   "scene_device_bytes": info["device_bytes"], "scene_setup_s": round(setup_s, 3)},
+        "ms_per_frame": round(elapsed / K * 1e3, 4),
+        "mpaths_per_s": round(W * H * K / elapsed / 1e6, 3),
+        "rays_per_step": rays / K,
+        "segments_per_step": segments / K,
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "kernel": "k_pt_pass", "kernel_avg_ms": round(avg_kernel_ms, 4), "launches": launches,
+                     "algorithmic_bytes_per_launch": my_alg_bytes / K,
+                     "algorithmic_bytes_per_ray": round(alg_bytes / rays, 1) if rays else None},
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,372 @@
+"""ctypes bindings of lib/libgpuart.so (C++ host library, capi.h) and lib/libgpuart_hip.so
+(device back end, include/gpuart_hip.h). Plumbing only — no computation happens here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(HERE, "lib")
+HIP_LIB = os.path.join(LIBDIR, "libgpuart_hip.so")
+HOST_LIB = os.path.join(LIBDIR, "libgpuart.so")
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class PrimDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("f", C.c_float * 9)]
+
+
+class Params(C.Structure):
+    _fields_ = [("sunDirAlt", C.c_float * 4), ("sunEnabled", C.c_int32), ("userSphere", C.c_float * 4),
+                ("userSphereEm", C.c_float * 3), ("userSphereFlags", C.c_uint32), ("pixelSize", C.c_float),
+                ("cameraPos", C.c_float * 3), ("maxSegments", C.c_int32), ("minWeight", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("prim_tests", C.c_uint64 * 4), ("segments", C.c_uint64)]
+
+    def algorithmic_bytes(self):
+        """48 B per distinct node + (16 + 16*len) B per tested primitive."""
+        p = self.prim_tests
+        return 48 * self.nodes + 32 * p[0] + 48 * p[1] + 64 * p[2] + 80 * p[3]
+
+    def as_dict(self):
+        return dict(rays=self.rays, nodes=self.nodes, prim_tests=list(self.prim_tests), segments=self.segments,
+                    algorithmic_bytes=self.algorithmic_bytes())
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """libgpuart_hip.so; raises NativeLibraryMissing if it has not been built (no fallback)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise NativeLibraryMissing("%s not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                       "(make -C gpuart_amd/csrc); there is no CPU fallback" % HIP_LIB)
+        L = C.CDLL(HIP_LIB, mode=C.RTLD_GLOBAL)
+        L.gpuart_hip_last_error.restype = C.c_char_p
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        if not os.path.exists(HOST_LIB):
+            raise NativeLibraryMissing("%s not found — run make -C gpuart_amd/csrc" % HOST_LIB)
+        L = C.CDLL(HOST_LIB)
+        L.gpuart_renderer_create.restype = C.c_void_p
+        L.gpuart_renderer_backend.restype = C.c_void_p
+        L.gpuart_renderer_path_tracing_pass.restype = C.c_uint
+        for name in ["destroy", "is_ok", "set_primitives", "init_box", "init_dragon", "set_camera", "update_viewport",
+                     "set_tile", "set_sun", "set_user_sphere", "set_max_path_segments", "set_seed", "render_direct",
+                     "restart_path_tracing", "path_tracing_pass", "read_direct", "read_radiance", "finish", "backend",
+                     "params", "scene_info"]:
+            getattr(L, "gpuart_renderer_" + name).argtypes = None
+        _host = L
+    return _host
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def make_prims(descs):
+    arr = (PrimDesc * len(descs))()
+    for i, (t, f) in enumerate(descs):
+        arr[i].type = t
+        for k, v in enumerate(f):
+            arr[i].f[k] = v
+    return arr
+
+
+# ---- pure host functions ------------------------------------------------------------------------
+def compile_bvh(descs, max_levels=1024, min_prims=2):
+    """BoundingVolumesHierarchy(prims, max_levels, min_prims).Compile() -> (quads (n,4) float32, depth)."""
+    L = host_lib()
+    arr = descs if isinstance(descs, C.Array) else make_prims(descs)
+    q = C.POINTER(C.c_float)()
+    nq = C.c_size_t(0)
+    depth = C.c_uint(0)
+    rc = L.gpuart_compile_bvh(arr, C.c_int(len(arr)), C.c_uint(max_levels), C.c_uint(min_prims), C.byref(q), C.byref(nq),
+                              C.byref(depth))
+    if rc != 0:
+        raise RuntimeError("gpuart_compile_bvh failed")
+    out = np.ctypeslib.as_array(q, shape=(nq.value, 4)).copy()
+    L.gpuart_free(q)
+    return out, depth.value
+
+
+def compile_bvh_from_file(kind, path, magnification=1.0, translation=(0, 0, 0), extra=()):
+    """kind: 'ply' or 'dat'. Returns (quads, depth, nloaded)."""
+    L = host_lib()
+    ex = make_prims(list(extra))
+    q = C.POINTER(C.c_float)()
+    nq = C.c_size_t(0)
+    depth = C.c_uint(0)
+    nl = C.c_size_t(0)
+    rc = L.gpuart_compile_bvh_from_file(C.c_int(0 if kind == "ply" else 1), path.encode(), C.c_float(magnification),
+                                        _f3(translation), ex, C.c_int(len(ex)), C.byref(q), C.byref(nq), C.byref(depth),
+                                        C.byref(nl))
+    if rc != 0:
+        raise RuntimeError("loading %s failed" % path)
+    out = np.ctypeslib.as_array(q, shape=(nq.value, 4)).copy()
+    L.gpuart_free(q)
+    return out, depth.value, nl.value
+
+
+def camera_basis(pos, dir, up, fov_y, screen_dist, W, H):
+    out = np.zeros(13, np.float32)
+    host_lib().gpuart_camera_basis(_f3(pos), _f3(dir), _f3(up), C.c_float(fov_y), C.c_float(screen_dist), C.c_uint(W),
+                                   C.c_uint(H), _p(out))
+    return out
+
+
+def sun_direction(az, alt):
+    out = (C.c_float * 3)()
+    host_lib().gpuart_sun_direction(C.c_float(az), C.c_float(alt), out)
+    return np.array(list(out), np.float32)
+
+
+# ---- device back end (include/gpuart_hip.h) -----------------------------------------------------------
+class HipError(RuntimeError):
+    pass
+
+
+class Backend:
+    """A gpuart_hip_ctx. Owns the context unless constructed from a borrowed pointer."""
+
+    def __init__(self, device=0, borrowed=None):
+        self.L = hip_lib()
+        self.owned = borrowed is None
+        if borrowed is None:
+            ctx = C.c_void_p()
+            self._chk(self.L.gpuart_hip_create(C.c_int(device), C.byref(ctx)))
+            self.ctx = ctx
+        else:
+            self.ctx = C.c_void_p(borrowed)
+        self.tile = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError("gpuart_hip error %d: %s" % (rc, self.L.gpuart_hip_last_error().decode()))
+
+    def close(self):
+        if self.owned and self.ctx:
+            self.L.gpuart_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # frame / scene / camera
+    def resize(self, W, H):
+        self._chk(self.L.gpuart_hip_resize(self.ctx, C.c_uint32(W), C.c_uint32(H)))
+        self.tile = (0, 0, W, H)
+
+    def set_tile(self, x0, y0, tw, th):
+        self._chk(self.L.gpuart_hip_set_tile(self.ctx, C.c_uint32(x0), C.c_uint32(y0), C.c_uint32(tw), C.c_uint32(th)))
+        self.tile = (x0, y0, tw, th)
+
+    def upload_bvh(self, quads):
+        quads = np.ascontiguousarray(quads, np.float32)
+        self._chk(self.L.gpuart_hip_upload_bvh(self.ctx, _p(quads), C.c_size_t(quads.size // 4)))
+
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(cam, np.float32)
+        self._chk(self.L.gpuart_hip_set_camera(self.ctx, _f3(cam[0:3]), _f3(cam[3:6]), _f3(cam[6:9]), _f3(cam[9:12])))
+
+    # rendering
+    def render_direct(self, params):
+        self._chk(self.L.gpuart_hip_render_direct(self.ctx, C.byref(params)))
+
+    def pt_reset(self):
+        self._chk(self.L.gpuart_hip_pt_reset(self.ctx))
+
+    def pt_pass(self, params, rand_seed, npaths):
+        rs = (C.c_float * 4)(*[float(x) for x in rand_seed])
+        self._chk(self.L.gpuart_hip_pt_pass(self.ctx, C.byref(params), rs, C.c_int(npaths)))
+
+    def read(self, which, divide_by=1.0):
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.float32)
+        self._chk(self.L.gpuart_hip_read(self.ctx, C.c_int(which), _p(out), C.c_float(divide_by)))
+        return out
+
+    def export(self, which, device_ptr, divide_by=1.0):
+        self._chk(self.L.gpuart_hip_export(self.ctx, C.c_int(which), C.c_void_p(device_ptr), C.c_float(divide_by)))
+
+    def finish(self):
+        self._chk(self.L.gpuart_hip_finish(self.ctx))
+
+    def set_mode(self, reference_work):
+        self._chk(self.L.gpuart_hip_set_mode(self.ctx, C.c_int(1 if reference_work else 0)))
+
+    def counters(self, reset=False):
+        c = Counters()
+        self._chk(self.L.gpuart_hip_counters(self.ctx, C.byref(c), C.c_int(1 if reset else 0)))
+        return c
+
+    def kernel_time(self, reset=False):
+        ms = C.c_double(0)
+        n = C.c_uint64(0)
+        self._chk(self.L.gpuart_hip_kernel_time(self.ctx, C.byref(ms), C.byref(n), C.c_int(1 if reset else 0)))
+        return ms.value, n.value
+
+    def scene_info(self):
+        nodes, prims, bytes_ = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        depth = C.c_uint32(0)
+        self._chk(self.L.gpuart_hip_scene_info(self.ctx, C.byref(nodes), C.byref(prims), C.byref(depth), C.byref(bytes_)))
+        return dict(nodes=nodes.value, prims=prims.value, max_depth=depth.value, device_bytes=bytes_.value)
+
+    # test hooks
+    def _hook(self, name, ins, nout, *extra):
+        ins = [np.ascontiguousarray(a, np.float32) for a in ins]
+        n = ins[0].shape[0]
+        outs = [np.zeros((n, 4), np.float32) for _ in range(nout)]
+        self._chk(getattr(self.L, name)(self.ctx, *[_p(a) for a in ins], *extra, C.c_int(n), *[_p(o) for o in outs]))
+        return outs
+
+    def test_random(self, x): return self._hook("gpuart_hip_test_random", [x], 1)[0]
+    def test_math(self, x): return self._hook("gpuart_hip_test_math", [x], 1)[0]
+    def test_hemisphere(self, v, ri): return self._hook("gpuart_hip_test_hemisphere", [v, ri], 1)[0]
+
+    def test_inside_cone(self, v, nrm, ri, half_angle):
+        return self._hook("gpuart_hip_test_inside_cone", [v, nrm, ri], 1, C.c_float(half_angle))[0]
+
+    def test_sky(self, dirs, sun_dir_alt):
+        return self._hook("gpuart_hip_test_sky", [dirs], 1, (C.c_float * 4)(*[float(x) for x in sun_dir_alt]))[0]
+
+    def test_intersect(self, ptype, rs, rd, quads16):
+        rs = np.ascontiguousarray(rs, np.float32)
+        rd = np.ascontiguousarray(rd, np.float32)
+        q = np.ascontiguousarray(quads16, np.float32).reshape(rs.shape[0], 16)
+        n = rs.shape[0]
+        o0, o1 = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+        self._chk(self.L.gpuart_hip_test_intersect(self.ctx, C.c_int(ptype), _p(rs), _p(rd), _p(q), C.c_int(n), _p(o0), _p(o1)))
+        return o0, o1
+
+    def test_aabb(self, rs, rd, bmin, bmax): return self._hook("gpuart_hip_test_aabb", [rs, rd, bmin, bmax], 1)[0]
+
+    def test_traverse(self, rs, rd, user_sphere, any_hit=False):
+        rs = np.ascontiguousarray(rs, np.float32)
+        rd = np.ascontiguousarray(rd, np.float32)
+        n = rs.shape[0]
+        o0, o1 = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+        us = (C.c_float * 4)(*[float(x) for x in user_sphere])
+        self._chk(self.L.gpuart_hip_test_traverse(self.ctx, _p(rs), _p(rd), us, C.c_int(n), C.c_int(1 if any_hit else 0),
+                                                  _p(o0), _p(o1)))
+        return o0, o1
+
+    def test_cam_rays(self):
+        _, _, tw, th = self.tile
+        rs, rd = np.zeros((th, tw, 4), np.float32), np.zeros((th, tw, 4), np.float32)
+        self._chk(self.L.gpuart_hip_test_cam_rays(self.ctx, _p(rs), _p(rd)))
+        return rs, rd
+
+
+# ---- gpuart::Renderer ------------------------------------------------------------------------------
+class Renderer:
+    """Python handle of the C++ gpuart::Renderer (reference API, src/renderer.h:183-296)."""
+
+    def __init__(self, W, H, cam, device=0):
+        self.L = host_lib()
+        self.W, self.H = W, H
+        self.tile = (0, 0, W, H)
+        self.h = C.c_void_p(self.L.gpuart_renderer_create(C.c_uint(W), C.c_uint(H), _f3(cam["pos"]), _f3(cam["dir"]),
+                                                          _f3(cam["up"]), C.c_float(cam["fov_y"]),
+                                                          C.c_float(cam["screen_dist"]), C.c_int(device)))
+        if not self.L.gpuart_renderer_is_ok(self.h):
+            msg = hip_lib().gpuart_hip_last_error().decode()
+            self.L.gpuart_renderer_destroy(self.h)
+            self.h = None
+            raise HipError("Renderer initialisation failed: " + msg)
+        self.backend = Backend(borrowed=self.L.gpuart_renderer_backend(self.h))
+        self.backend.tile = self.tile
+
+    def close(self):
+        if self.h:
+            self.L.gpuart_renderer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_ok(self): return bool(self.L.gpuart_renderer_is_ok(self.h))
+
+    def set_primitives(self, descs, print_info=False):
+        arr = descs if isinstance(descs, C.Array) else make_prims(descs)
+        self.L.gpuart_renderer_set_primitives(self.h, arr, C.c_int(len(arr)), C.c_int(1 if print_info else 0))
+
+    def init_box(self): self.L.gpuart_renderer_init_box(self.h)
+    def init_dragon(self, path): return bool(self.L.gpuart_renderer_init_dragon(self.h, path.encode()))
+
+    def set_camera(self, cam):
+        return bool(self.L.gpuart_renderer_set_camera(self.h, _f3(cam["pos"]), _f3(cam["dir"]), _f3(cam["up"]),
+                                                      C.c_float(cam["fov_y"]), C.c_float(cam["screen_dist"])))
+
+    def update_viewport(self, W, H):
+        ok = bool(self.L.gpuart_renderer_update_viewport(self.h, C.c_uint(W), C.c_uint(H)))
+        self.W, self.H = W, H
+        self.tile = self.backend.tile = (0, 0, W, H)
+        return ok
+
+    def set_tile(self, x0, y0, w, h):
+        ok = bool(self.L.gpuart_renderer_set_tile(self.h, C.c_uint(x0), C.c_uint(y0), C.c_uint(w), C.c_uint(h)))
+        if ok:
+            self.tile = self.backend.tile = (x0, y0, w, h)
+        return ok
+
+    def set_sun(self, az, alt, direct=True):
+        self.L.gpuart_renderer_set_sun(self.h, C.c_float(az), C.c_float(alt), C.c_int(1 if direct else 0))
+
+    def set_user_sphere(self, pos, radius, emittance=0.0, specular=False, fuzzy=False):
+        self.L.gpuart_renderer_set_user_sphere(self.h, _f3(pos), C.c_float(radius), C.c_float(emittance),
+                                               C.c_int(int(specular)), C.c_int(int(fuzzy)))
+
+    def set_max_path_segments(self, n): self.L.gpuart_renderer_set_max_path_segments(self.h, C.c_uint(n))
+    def set_seed(self, seed): self.L.gpuart_renderer_set_seed(self.h, C.c_uint32(seed))
+    def render_direct(self): self.L.gpuart_renderer_render_direct(self.h)
+
+    def restart_path_tracing(self, per_pass, per_pixel):
+        self.L.gpuart_renderer_restart_path_tracing(self.h, C.c_uint(per_pass), C.c_uint(per_pixel))
+
+    def path_tracing_pass(self): return int(self.L.gpuart_renderer_path_tracing_pass(self.h))
+
+    def read_direct(self):
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.float32)
+        if not self.L.gpuart_renderer_read_direct(self.h, _p(out)):
+            raise HipError("read_direct failed")
+        return out
+
+    def read_radiance(self, normalized=False):
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.float32)
+        if not self.L.gpuart_renderer_read_radiance(self.h, _p(out), C.c_int(1 if normalized else 0)):
+            raise HipError("read_radiance failed")
+        return out
+
+    def finish(self): return bool(self.L.gpuart_renderer_finish(self.h))
+
+    def params(self):
+        p = Params()
+        self.L.gpuart_renderer_params(self.h, C.byref(p))
+        return p

@@ -1,0 +1,705 @@
+// gpuart_hip.hip — render kernels and the C-ABI launcher of libgpuart_hip.so (gfx950 only).
+// See include/gpuart_hip.h for the boundary and DESIGN.md for layout / kernel notes.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_shade.h"
+#include "gpuart_hip.h"
+
+using namespace gd;
+
+#define STACK_DEPTH 32
+#define BLOCK 64  // one wavefront per workgroup: an 8x8 pixel tile
+
+// =================================================================================================
+// Kernels
+// =================================================================================================
+namespace {
+
+GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned long long *g) {
+    // one atomic per counter per wavefront
+    uint32_t v[7] = {wc.rays, wc.nodes, wc.prims[0], wc.prims[1], wc.prims[2], wc.prims[3], segments};
+    for (int k = 0; k < 7; k++) {
+        unsigned long long s = v[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[k], s);
+    }
+}
+
+GD_FN bool tile_pixel(const Frame &f, uint32_t &lx, uint32_t &ly) {
+    // block -> 8x8 pixel tile, thread -> pixel inside it (row-major within the tile)
+    uint32_t tiles_x = (f.tw + 7) / 8;
+    uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    lx = bx * 8 + (threadIdx.x & 7);
+    ly = by * 8 + (threadIdx.x >> 3);
+    return lx < f.tw && ly < f.th;
+}
+
+template <bool REFWORK, bool STACKLESS>
+__global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_params P, float4 *__restrict__ out,
+                                                  unsigned long long *counters) {
+    __shared__ uint2 stack[STACKLESS ? 1 : STACK_DEPTH][BLOCK];
+    uint32_t lx, ly;
+    bool active = tile_pixel(f, lx, ly);
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    if (active) {
+        F3 rs, rd;
+        camera_ray(f, f.x0 + lx, f.y0 + ly, rs, rd);
+        F3 c = direct_lighting_pixel<REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, P, rs, rd, stack, threadIdx.x, &wc);
+        out[(size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 1.0f);
+    }
+    if (REFWORK) flush_counters(wc, 0, counters);
+}
+
+template <bool REFWORK, bool STACKLESS>
+__global__ void __launch_bounds__(BLOCK) k_pt_pass(Scene sc, Frame f, gpuart_params P, float4 seed, int npaths,
+                                                   float4 *__restrict__ accum, unsigned long long *counters) {
+    __shared__ uint2 stack[STACKLESS ? 1 : STACK_DEPTH][BLOCK];
+    uint32_t lx, ly;
+    bool active = tile_pixel(f, lx, ly);
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    uint32_t segments = 0;
+    if (active) {
+        F3 rs, rd;
+        camera_ray(f, f.x0 + lx, f.y0 + ly, rs, rd);
+        F3 c = path_tracing_pixel<REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, P, seed, npaths, rs, rd, stack, threadIdx.x,
+                                                                          &wc, segments);
+        size_t idx = (size_t)ly * f.tw + lx;
+        float4 prev = accum[idx];
+        accum[idx] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
+    }
+    if (REFWORK) flush_counters(wc, segments, counters);
+}
+
+__global__ void k_scale_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n, float divide_by) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float4 v = src[i];
+        dst[i] = make_float4(v.x / divide_by, v.y / divide_by, v.z / divide_by, v.w);
+    }
+}
+
+// ---- test-hook kernels ---------------------------------------------------------------------------
+__global__ void k_test_random(const float4 *in, int n, float4 *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = in[i];
+    out[i] = make_float4(random1(v.x), random2(v.x, v.y), random3(f3(v.x, v.y, v.z)), random4(v));
+}
+__global__ void k_test_math(const float4 *in, int n, float4 *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    sincos_lp(in[i].x, s, c);
+    out[i] = make_float4(s, c, pow_lp(in[i].y, 16.0f), sqrtf(in[i].y));
+}
+__global__ void k_test_hemisphere(const float4 *v, const float4 *ri, int n, float4 *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 r = random_hemisphere_direction(xyz(v[i]), xyz(ri[i]));
+    out[i] = make_float4(r.x, r.y, r.z, 0);
+}
+__global__ void k_test_inside_cone(const float4 *v, const float4 *nrm, const float4 *ri, float ha, int n, float4 *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 r = random_direction_inside_cone(xyz(v[i]), xyz(nrm[i]), ha, xyz(ri[i]));
+    out[i] = make_float4(r.x, r.y, r.z, 0);
+}
+struct Float4Arg { float v[4]; };
+__global__ void k_test_sky(const float4 *dir, Float4Arg sda, int n, float4 *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 r = sky_color(xyz(dir[i]), sda.v);
+    out[i] = make_float4(r.x, r.y, r.z, 0);
+}
+/// recs: n device-layout primitive records (3 quads each)
+__global__ void k_test_intersect(const float4 *rs, const float4 *rd, const float4 *recs, int n, float4 *o0, float4 *o1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
+    float pos; F3 p = f3(0, 0, 0), nn = f3(0, 0, 0); int t;
+    prim_hit(r, recs[3 * i], recs[3 * i + 1], recs[3 * i + 2], pos, p, nn, t);
+    if (pos > 0) { o0[i] = make_float4(pos, p.x, p.y, p.z); o1[i] = make_float4(nn.x, nn.y, nn.z, 0); }
+    else { o0[i] = make_float4(pos, 0, 0, 0); o1[i] = make_float4(0, 0, 0, 0); }
+}
+__global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bmin, const float4 *bmax, int n, float4 *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
+    float pos;
+    bool h = aabb_entry(r, f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z), xyz(bmin[i]), xyz(bmax[i]), pos);
+    out[i] = make_float4(h ? 1.0f : 0.0f, h ? pos : 0.0f, 0, 0);
+}
+template <bool ANY, bool STACKLESS>
+__global__ void __launch_bounds__(BLOCK) k_test_traverse(Scene sc, const float4 *rs, const float4 *rd, Float4Arg us, int n,
+                                                         float4 *o0, float4 *o1) {
+    __shared__ uint2 stack[STACKLESS ? 1 : STACK_DEPTH][BLOCK];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
+    float closest; uint32_t prim;
+    bvh_query<ANY, false, STACKLESS, STACK_DEPTH, BLOCK>(sc, r, stack, threadIdx.x, closest, prim, nullptr);
+    if (ANY) {
+        o0[i] = make_float4(prim != GD_NO_PRIM ? 1.0f : 0.0f, 0, 0, 0);
+        o1[i] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    Surface h; h.p = f3(0, 0, 0); h.n = f3(0, 0, 0);
+    bool ush;
+    resolve_hit(sc, r, closest, prim, us.v, h, ush);
+    if (h.ptype >= 0) {
+        o0[i] = make_float4(h.pos, h.p.x, h.p.y, h.p.z);
+        o1[i] = make_float4(h.n.x, h.n.y, h.n.z, (float)h.ptype + (ush ? 0.5f : 0.0f));
+    } else {
+        o0[i] = make_float4(-1, 0, 0, 0);
+        o1[i] = make_float4(0, 0, 0, -1);
+    }
+}
+__global__ void k_test_cam_rays(Frame f, float4 *rstart, float4 *rdir) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.tw * f.th) return;
+    uint32_t lx = i % f.tw, ly = i / f.tw;
+    F3 s, d;
+    camera_ray(f, f.x0 + lx, f.y0 + ly, s, d);
+    rstart[i] = make_float4(s.x, s.y, s.z, 0);
+    rdir[i] = make_float4(d.x, d.y, d.z, 0);
+}
+
+}  // namespace
+
+// =================================================================================================
+// Host side: context, upload, launches
+// =================================================================================================
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(GPUART_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// llvmpipe's plane equation of one interpolated attribute over one triangle (DESIGN.md "UV").
+void plane_coef(float x0, float y0, float x1, float y1, float x2, float y2, float a0, float a1, float a2, float c[3]) {
+    float x0c = x0 - 0.5f, y0c = y0 - 0.5f;
+    float dx01 = x0 - x1, dy01 = y0 - y1, dx20 = x2 - x0, dy20 = y2 - y0;
+    float e = dx01 * dy20, f = dy01 * dx20;
+    float ooa = 1.0f / (e - f);
+    float dy20o = dy20 * ooa, dy01o = dy01 * ooa, dx20o = dx20 * ooa, dx01o = dx01 * ooa;
+    float da01 = a0 - a1, da20 = a2 - a0;
+    float dadx = da01 * dy20o - da20 * dy01o;
+    float dady = da20 * dx01o - da01 * dx20o;
+    c[0] = a0 - (dadx * x0c + dady * y0c);
+    c[1] = dadx;
+    c[2] = dady;
+}
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct gpuart_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Frame frame{};
+    bool have_camera = false, have_scene = false;
+    float4 *d_nodes = nullptr, *d_prims = nullptr;
+    uint32_t *d_parent = nullptr;
+    uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
+    uint32_t max_depth = 0;
+    float4 *d_direct = nullptr, *d_accum = nullptr;
+    size_t tile_pixels = 0;
+    unsigned long long *d_counters = nullptr;
+    int reference_work = 0;
+    std::vector<TimedLaunch> pending, free_events;
+    double timed_ms = 0;
+    uint64_t timed_launches = 0;
+    float *d_scratch = nullptr;  // test hooks
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int realloc_tile(gpuart_hip_ctx *c) {
+    if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; }
+    if (c->d_accum) { (void)hipFree(c->d_accum); c->d_accum = nullptr; }
+    c->tile_pixels = (size_t)c->frame.tw * c->frame.th;
+    if (!c->tile_pixels) return 0;
+    HIP_TRY(hipMalloc(&c->d_direct, c->tile_pixels * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->d_accum, c->tile_pixels * sizeof(float4)));
+    HIP_TRY(hipMemsetAsync(c->d_direct, 0, c->tile_pixels * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
+    return 0;
+}
+
+void update_uv(gpuart_hip_ctx *c) {
+    float w = (float)c->frame.W, h = (float)c->frame.H;
+    float *k = c->frame.uv_coef;
+    plane_coef(w, 0, 0, 0, w, h, 1, 0, 1, k + 0);  // A.u (V1,V0,V2)
+    plane_coef(w, 0, 0, 0, w, h, 0, 0, 1, k + 3);  // A.v
+    plane_coef(w, h, 0, 0, 0, h, 1, 0, 0, k + 6);  // B.u (V2,V0,V3)
+    plane_coef(w, h, 0, 0, 0, h, 1, 0, 1, k + 9);  // B.v
+}
+
+Scene scene_of(const gpuart_hip_ctx *c) {
+    Scene s;
+    s.nodes = c->d_nodes;
+    s.prims = c->d_prims;
+    s.parent = c->d_parent;
+    s.num_nodes = (uint32_t)c->n_nodes;
+    s.max_depth = c->max_depth;
+    return s;
+}
+
+bool stackless(const gpuart_hip_ctx *c) { return c->max_depth > STACK_DEPTH; }
+
+int fold_timings(gpuart_hip_ctx *c) {
+    for (auto &t : c->pending) {
+        HIP_TRY(hipEventSynchronize(t.stop));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+        c->timed_ms += ms;
+        c->timed_launches++;
+        c->free_events.push_back(t);
+    }
+    c->pending.clear();
+    return 0;
+}
+
+int begin_timed(gpuart_hip_ctx *c, TimedLaunch &t) {
+    if (c->pending.size() >= 512) { int r = fold_timings(c); if (r) return r; }
+    if (!c->free_events.empty()) { t = c->free_events.back(); c->free_events.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&t.start)); HIP_TRY(hipEventCreate(&t.stop)); }
+    HIP_TRY(hipEventRecord(t.start, c->stream));
+    return 0;
+}
+int end_timed(gpuart_hip_ctx *c, TimedLaunch &t) {
+    HIP_TRY(hipEventRecord(t.stop, c->stream));
+    c->pending.push_back(t);
+    return 0;
+}
+
+// ---- canonical tree -> device layout ---------------------------------------------------------------
+struct Converter {
+    const float *q;
+    size_t nq;
+    std::vector<float4> nodes, prims;
+    std::vector<uint32_t> parent;
+    uint32_t max_depth = 0;
+    std::string err;
+
+    static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+    static float fbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+    /// Appends the device record of one canonical primitive payload (type + data quads).
+    static bool pack_prim(uint32_t type, const float *d, float4 rec[3]) {
+        float T = fbits(type);
+        switch (type) {
+        case P_SPHERE:
+            rec[0] = make_float4(d[0], d[1], d[2], T); rec[1] = make_float4(d[3], 0, 0, 0); rec[2] = make_float4(0, 0, 0, 0);
+            return true;
+        case P_DISC:
+            rec[0] = make_float4(d[0], d[1], d[2], T); rec[1] = make_float4(d[4], d[5], d[6], d[3]); rec[2] = make_float4(0, 0, 0, 0);
+            return true;
+        case P_TRIANGLE:
+            rec[0] = make_float4(d[0], d[1], d[2], T);
+            rec[1] = make_float4(d[4] - d[0], d[5] - d[1], d[6] - d[2], 0);   // edge1 = v1 - v0
+            rec[2] = make_float4(d[8] - d[0], d[9] - d[1], d[10] - d[2], 0);  // edge2 = v2 - v0
+            return true;
+        case P_CONE:
+            rec[0] = make_float4(d[0], d[1], d[2], T);
+            rec[1] = make_float4(d[8], d[9], d[10], d[11]);
+            rec[2] = make_float4(d[3], d[12], d[13], d[14]);
+            return true;
+        }
+        return false;
+    }
+
+    bool node(size_t addr, uint32_t parentOrd, bool isLower, uint32_t depth) {
+        if (addr + 3 > nq) { err = "node address out of range"; return false; }
+        if (depth > 1024) { err = "tree deeper than 1024 levels"; return false; }
+        if (depth > max_depth) max_depth = depth;
+        uint32_t ord = (uint32_t)(nodes.size() / 2);
+        const float *b = q + 4 * addr;
+        uint32_t flags = bits(b[8]);
+        nodes.push_back(make_float4(b[0], b[1], b[2], 0));
+        nodes.push_back(make_float4(b[4], b[5], b[6], 0));
+        parent.push_back(parentOrd | (isLower ? 0x80000000u : 0u));
+        if (flags & 0x80000000u) {
+            uint32_t n = flags & ~0xE0000000u;
+            uint32_t first = (uint32_t)(prims.size() / 3);
+            size_t a = addr + 3;
+            static const int LEN[4] = {1, 2, 3, 4};
+            for (uint32_t i = 0; i < n; i++) {
+                if (a + 1 > nq) { err = "primitive header out of range"; return false; }
+                uint32_t type = bits(q[4 * a]);
+                if (type > 3) { err = "unknown primitive type"; return false; }
+                if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
+                float4 rec[3];
+                pack_prim(type, q + 4 * (a + 1), rec);
+                prims.push_back(rec[0]); prims.push_back(rec[1]); prims.push_back(rec[2]);
+                a += 1 + LEN[type];
+            }
+            nodes[2 * ord].w = fbits(first);
+            nodes[2 * ord + 1].w = fbits(0x80000000u | n);
+            return true;
+        }
+        uint32_t lo = bits(b[9]), hi = bits(b[10]);
+        if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
+        if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
+        if (!node(lo, ord, true, depth + 1)) return false;
+        uint32_t hiOrd = (uint32_t)(nodes.size() / 2);
+        nodes[2 * ord].w = fbits(hiOrd);
+        nodes[2 * ord + 1].w = fbits(0);
+        return node(hi, ord, false, depth + 1);
+    }
+};
+
+template <class T>
+int upload_vec(gpuart_hip_ctx *c, T *&dst, const std::vector<T> &v) {
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    size_t bytes = (v.size() + 4) * sizeof(T);  // a little slack past the end
+    HIP_TRY(hipMalloc(&dst, bytes));
+    HIP_TRY(hipMemsetAsync(dst, 0, bytes, c->stream));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int ensure_scratch(gpuart_hip_ctx *c, size_t bytes) {
+    if (c->scratch_bytes >= bytes) return 0;
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+    return 0;
+}
+
+/// Runs a test kernel: copies `nin` (n x 4 float) inputs up, launches, copies `nout` outputs back.
+template <class Launch>
+int run_hook(gpuart_hip_ctx *c, int n, const float *const *ins, int nin, float *const *outs, int nout, Launch launch) {
+    if (!c || n < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t one = (size_t)n * 16;
+    int r = ensure_scratch(c, one * (nin + nout));
+    if (r) return r;
+    float4 *base = (float4 *)c->d_scratch;
+    std::vector<float4 *> di, dout;
+    for (int k = 0; k < nin; k++) {
+        di.push_back(base + (size_t)k * n);
+        HIP_TRY(hipMemcpyAsync(di[k], ins[k], one, hipMemcpyHostToDevice, c->stream));
+    }
+    for (int k = 0; k < nout; k++) dout.push_back(base + (size_t)(nin + k) * n);
+    launch(di, dout);
+    HIP_TRY(hipGetLastError());
+    for (int k = 0; k < nout; k++) HIP_TRY(hipMemcpyAsync(outs[k], dout[k], one, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gpuart_hip_last_error(void) { return g_last_error.c_str(); }
+
+int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
+    if (!out) return fail(GPUART_HIP_ERR_ARG, "out == NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(GPUART_HIP_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= count) return fail(GPUART_HIP_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GPUART_HIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    gpuart_hip_ctx *c = new (std::nothrow) gpuart_hip_ctx();
+    if (!c) return fail(GPUART_HIP_ERR_DEVICE, "out of host memory");
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
+    if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c; return fail(GPUART_HIP_ERR_DEVICE, "counter allocation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+int gpuart_hip_destroy(gpuart_hip_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_parent, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int gpuart_hip_resize(gpuart_hip_ctx *c, uint32_t width, uint32_t height) {
+    if (!c || width == 0 || height == 0 || width > 65536 || height > 65536) return fail(GPUART_HIP_ERR_ARG, "bad frame size");
+    HIP_TRY(hipSetDevice(c->device));
+    c->frame.W = width; c->frame.H = height;
+    c->frame.x0 = 0; c->frame.y0 = 0; c->frame.tw = width; c->frame.th = height;
+    update_uv(c);
+    return realloc_tile(c);
+}
+
+int gpuart_hip_set_tile(gpuart_hip_ctx *c, uint32_t x0, uint32_t y0, uint32_t tw, uint32_t th) {
+    if (!c || !c->frame.W) return fail(GPUART_HIP_ERR_ARG, "set_tile before resize");
+    if (tw == 0 || th == 0 || (uint64_t)x0 + tw > c->frame.W || (uint64_t)y0 + th > c->frame.H)
+        return fail(GPUART_HIP_ERR_ARG, "tile outside the frame");
+    HIP_TRY(hipSetDevice(c->device));
+    c->frame.x0 = x0; c->frame.y0 = y0; c->frame.tw = tw; c->frame.th = th;
+    return realloc_tile(c);
+}
+
+int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) {
+    if (!c || !quads || nquads < 3 || nquads > (1ull << 29)) return fail(GPUART_HIP_ERR_ARG, "bad tree");
+    HIP_TRY(hipSetDevice(c->device));
+    Converter cv;
+    cv.q = quads; cv.nq = nquads;
+    if (!cv.node(0, 0, false, 0)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
+    cv.parent[0] = 0;
+    int r;
+    if ((r = upload_vec(c, c->d_nodes, cv.nodes))) return r;
+    if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
+    if ((r = upload_vec(c, c->d_parent, cv.parent))) return r;
+    c->n_nodes = cv.nodes.size() / 2;
+    c->n_prims = cv.prims.size() / 3;
+    c->max_depth = cv.max_depth;
+    c->scene_bytes = cv.nodes.size() * 16 + cv.prims.size() * 16 + cv.parent.size() * 4;
+    c->have_scene = true;
+    return 0;
+}
+
+int gpuart_hip_set_camera(gpuart_hip_ctx *c, const float pos[3], const float bl[3], const float dh[3], const float dv[3]) {
+    if (!c || !pos || !bl || !dh || !dv) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    memcpy(c->frame.cam_pos, pos, 12); memcpy(c->frame.bottom_left, bl, 12);
+    memcpy(c->frame.delta_horz, dh, 12); memcpy(c->frame.delta_vert, dv, 12);
+    c->have_camera = true;
+    return 0;
+}
+
+static int check_ready(gpuart_hip_ctx *c, const gpuart_params *p) {
+    if (!c || !p) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (!c->have_scene) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
+    if (!c->have_camera) return fail(GPUART_HIP_ERR_ARG, "no camera set");
+    if (!c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    return 0;
+}
+
+int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
+    int r = check_ready(c, p);
+    if (r) return r;
+    HIP_TRY(hipSetDevice(c->device));
+    dim3 grid(((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8));
+    Scene sc = scene_of(c);
+    TimedLaunch t;
+    if ((r = begin_timed(c, t))) return r;
+    bool sl = stackless(c);
+    if (c->reference_work) {
+        if (sl) k_direct<true, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
+        else k_direct<true, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
+    } else {
+        if (sl) k_direct<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
+        else k_direct<false, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    return end_timed(c, t);
+}
+
+int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
+    if (!c || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
+    return 0;
+}
+
+int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float randSeed[4], int npaths) {
+    int r = check_ready(c, p);
+    if (r) return r;
+    if (!randSeed || npaths < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    dim3 grid(((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8));
+    Scene sc = scene_of(c);
+    float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
+    TimedLaunch t;
+    if ((r = begin_timed(c, t))) return r;
+    bool sl = stackless(c);
+    if (c->reference_work) {
+        if (sl) k_pt_pass<true, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
+        else k_pt_pass<true, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
+    } else {
+        if (sl) k_pt_pass<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
+        else k_pt_pass<false, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    return end_timed(c, t);
+}
+
+int gpuart_hip_export(gpuart_hip_ctx *c, int which, void *rgba_device, float divide_by) {
+    if (!c || !rgba_device || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const float4 *src = which == 0 ? c->d_direct : c->d_accum;
+    if (!(divide_by > 0)) divide_by = 1.0f;
+    size_t n = c->tile_pixels;
+    k_scale_copy<<<dim3((unsigned)((n + 255) / 256)), 256, 0, c->stream>>>(src, (float4 *)rgba_device, n, divide_by);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gpuart_hip_read(gpuart_hip_ctx *c, int which, float *rgba_host, float divide_by) {
+    if (!c || !rgba_host || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t bytes = c->tile_pixels * sizeof(float4);
+    const float4 *src = which == 0 ? c->d_direct : c->d_accum;
+    if (divide_by > 0 && divide_by != 1.0f) {
+        int r = ensure_scratch(c, bytes);
+        if (r) return r;
+        r = gpuart_hip_export(c, which, c->d_scratch, divide_by);
+        if (r) return r;
+        src = (const float4 *)c->d_scratch;
+    }
+    HIP_TRY(hipMemcpyAsync(rgba_host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gpuart_hip_finish(gpuart_hip_ctx *c) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gpuart_hip_set_mode(gpuart_hip_ctx *c, int reference_work) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    c->reference_work = reference_work ? 1 : 0;
+    return 0;
+}
+
+int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out) {
+        out->rays = h[0]; out->nodes = h[1];
+        for (int k = 0; k < 4; k++) out->prim_tests[k] = h[2 + k];
+        out->segments = h[6];
+    }
+    if (reset) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
+    return 0;
+}
+
+int gpuart_hip_kernel_time(gpuart_hip_ctx *c, double *total_ms, uint64_t *launches, int reset) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = fold_timings(c);
+    if (r) return r;
+    if (total_ms) *total_ms = c->timed_ms;
+    if (launches) *launches = c->timed_launches;
+    if (reset) { c->timed_ms = 0; c->timed_launches = 0; }
+    return 0;
+}
+
+int gpuart_hip_scene_info(gpuart_hip_ctx *c, uint64_t *nodes, uint64_t *prims, uint32_t *max_depth, uint64_t *device_bytes) {
+    if (!c || !c->have_scene) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
+    if (nodes) *nodes = c->n_nodes;
+    if (prims) *prims = c->n_prims;
+    if (max_depth) *max_depth = c->max_depth;
+    if (device_bytes) *device_bytes = c->scene_bytes;
+    return 0;
+}
+
+// ---- test hooks ------------------------------------------------------------------------------------
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), 256, 0, c->stream
+
+int gpuart_hip_test_random(gpuart_hip_ctx *c, const float *in, int n, float *out) {
+    const float *ins[] = {in}; float *outs[] = {out};
+    return run_hook(c, n, ins, 1, outs, 1, [&](auto &i, auto &o) { k_test_random<<<GRID1(n)>>>(i[0], n, o[0]); });
+}
+int gpuart_hip_test_math(gpuart_hip_ctx *c, const float *in, int n, float *out) {
+    const float *ins[] = {in}; float *outs[] = {out};
+    return run_hook(c, n, ins, 1, outs, 1, [&](auto &i, auto &o) { k_test_math<<<GRID1(n)>>>(i[0], n, o[0]); });
+}
+int gpuart_hip_test_hemisphere(gpuart_hip_ctx *c, const float *v, const float *ri, int n, float *out) {
+    const float *ins[] = {v, ri}; float *outs[] = {out};
+    return run_hook(c, n, ins, 2, outs, 1, [&](auto &i, auto &o) { k_test_hemisphere<<<GRID1(n)>>>(i[0], i[1], n, o[0]); });
+}
+int gpuart_hip_test_inside_cone(gpuart_hip_ctx *c, const float *v, const float *nrm, const float *ri, float ha, int n, float *out) {
+    const float *ins[] = {v, nrm, ri}; float *outs[] = {out};
+    return run_hook(c, n, ins, 3, outs, 1, [&](auto &i, auto &o) { k_test_inside_cone<<<GRID1(n)>>>(i[0], i[1], i[2], ha, n, o[0]); });
+}
+int gpuart_hip_test_sky(gpuart_hip_ctx *c, const float *dir, const float sda[4], int n, float *out) {
+    if (!sda) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    Float4Arg a; memcpy(a.v, sda, 16);
+    const float *ins[] = {dir}; float *outs[] = {out};
+    return run_hook(c, n, ins, 1, outs, 1, [&](auto &i, auto &o) { k_test_sky<<<GRID1(n)>>>(i[0], a, n, o[0]); });
+}
+int gpuart_hip_test_intersect(gpuart_hip_ctx *c, int ptype, const float *rs, const float *rd, const float *quads, int n,
+                              float *out0, float *out1) {
+    if (ptype < 0 || ptype > 3 || !quads || n < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    // canonical payload (4 quads per sample) -> device records, through the uploader's packer
+    std::vector<float4> recs((size_t)n * 3);
+    for (int i = 0; i < n; i++) Converter::pack_prim((uint32_t)ptype, quads + 16 * (size_t)i, &recs[3 * (size_t)i]);
+    // three record quads are passed as three n x 4 input arrays (de-interleaved), then re-read as records
+    std::vector<float> packed((size_t)n * 12);
+    memcpy(packed.data(), recs.data(), packed.size() * 4);
+    const float *ins[] = {rs, rd, packed.data(), packed.data() + (size_t)n * 4, packed.data() + (size_t)n * 8};
+    float *outs[] = {out0, out1};
+    // inputs 2,3,4 are contiguous in device scratch, so i[2] addresses all 3n quads
+    return run_hook(c, n, ins, 5, outs, 2, [&](auto &i, auto &o) { k_test_intersect<<<GRID1(n)>>>(i[0], i[1], i[2], n, o[0], o[1]); });
+}
+int gpuart_hip_test_aabb(gpuart_hip_ctx *c, const float *rs, const float *rd, const float *bmin, const float *bmax, int n, float *out) {
+    const float *ins[] = {rs, rd, bmin, bmax}; float *outs[] = {out};
+    return run_hook(c, n, ins, 4, outs, 1, [&](auto &i, auto &o) { k_test_aabb<<<GRID1(n)>>>(i[0], i[1], i[2], i[3], n, o[0]); });
+}
+int gpuart_hip_test_traverse(gpuart_hip_ctx *c, const float *rs, const float *rd, const float us[4], int n, int any_hit,
+                             float *out0, float *out1) {
+    if (!c || !c->have_scene || !us) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
+    Float4Arg a; memcpy(a.v, us, 16);
+    Scene sc = scene_of(c);
+    bool sl = stackless(c);
+    const float *ins[] = {rs, rd}; float *outs[] = {out0, out1};
+    return run_hook(c, n, ins, 2, outs, 2, [&](auto &i, auto &o) {
+        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
+        if (any_hit) {
+            if (sl) k_test_traverse<true, true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
+            else k_test_traverse<true, false><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
+        } else {
+            if (sl) k_test_traverse<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
+            else k_test_traverse<false, false><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
+        }
+    });
+}
+int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
+    if (!c || !c->have_camera || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "camera / frame not set");
+    int n = (int)c->tile_pixels;
+    float *outs[] = {rstart, rdir};
+    Frame f = c->frame;
+    return run_hook(c, n, nullptr, 0, outs, 2, [&](auto &, auto &o) { k_test_cam_rays<<<GRID1(n)>>>(f, o[0], o[1]); });
+}
+
+}  // extern "C"

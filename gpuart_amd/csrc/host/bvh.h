@@ -1,0 +1,66 @@
+// bvh.h — AABB bounding-volume hierarchy of the Renderer/Scene API.
+// Public surface as in the reference (src/bvh.h:46-93): construct from a primitive list with
+// (maxNumLevels, minPrimitivesPerNode), Compile() into the canonical RGBA32F quad array, Print().
+// Internals are different: the tree is a flat pre-order node vector that already owns the
+// serialised leaf payloads, so nothing dangles after the caller deletes its primitives.
+#ifndef GPUART_BVH_H
+#define GPUART_BVH_H
+
+#include <cstdint>
+#include <iosfwd>
+#include <vector>
+
+#include "core.h"
+
+namespace gpuart {
+
+class BoundingVolumesHierarchy {
+public:
+    // Node flags of the compiled format (reference src/bvh.h:48-52)
+    static const uint32_t LEAF = 1u << 31;
+    static const uint32_t IS_LOWER = 1u << 30;
+    static const uint32_t IS_ROOT = 1u << 29;
+    static const uint32_t FLAGS_MASK = LEAF | IS_LOWER | IS_ROOT;
+
+    BoundingVolumesHierarchy() = default;
+    BoundingVolumesHierarchy(const BoundingVolumesHierarchy &) = delete;
+    BoundingVolumesHierarchy &operator=(const BoundingVolumesHierarchy &) = delete;
+    BoundingVolumesHierarchy(BoundingVolumesHierarchy &&) = default;
+    BoundingVolumesHierarchy &operator=(BoundingVolumesHierarchy &&) = default;
+
+    /// Builds the tree. The order of elements in `primitives` may change.
+    BoundingVolumesHierarchy(std::vector<Primitive *> &primitives, unsigned maxNumLevels, unsigned minPrimitivesPerNode);
+
+    /// Appends the compiled tree to `compiledTree`:
+    ///   node      = {xmin,ymin,zmin,pad}{xmax,ymax,zmax,pad}{flags|count, lo, hi, parent}   (uint bits in floats,
+    ///               addresses in quads; the lower child follows its parent; leaves have lo = hi = 0.0f)
+    ///   leaf data = per primitive {type,pad,pad,pad} + payload (Primitive::StoreIntoBVH)
+    void Compile(Primitive::Data &compiledTree) const;
+
+    /// Prints a compiled tree, decoding it the way the device code does.
+    static void Print(const Primitive::Data &compiledTree, std::ostream &s);
+
+    size_t GetNumNodes() const { return Nodes.size(); }
+    size_t GetNumPrimitives() const { return NumPrimitives; }
+    unsigned GetDepth() const { return Depth; }  ///< level of the deepest node (root = 0)
+
+private:
+    struct Node {
+        float lo[3], hi[3];
+        uint32_t parent;        ///< index of the parent node (root: 0)
+        uint32_t higher;        ///< index of the upper child; 0 for leaves (the lower child is index+1)
+        bool isLower;
+        uint32_t count;         ///< primitives in a leaf (0 = interior node)
+        size_t dataBegin, dataEnd;  ///< leaf payload range in LeafData (floats)
+    };
+    std::vector<Node> Nodes;          ///< pre-order
+    std::vector<float> LeafData;      ///< serialised primitives of all leaves, in leaf order
+    size_t NumPrimitives = 0;
+    unsigned Depth = 0;
+
+    void Subdivide(std::vector<Primitive *> &prims, size_t from, size_t to, unsigned level, unsigned maxNumLevels,
+                   unsigned minPrimitivesPerNode, uint32_t parent, bool isLower);
+};
+
+}  // namespace gpuart
+#endif

@@ -1,0 +1,217 @@
+// renderer.cpp — host control of the hot path over the C-ABI device back end.
+#include "renderer.h"
+
+#include <algorithm>
+#include <chrono>
+#include <iomanip>
+#include <iostream>
+
+#include "utils.h"
+
+#define GPUART_PI 3.1415926f  // the reference's PI (src/renderer.cpp:48); feeds tan() of the field of view
+
+namespace gpuart {
+
+// ---- pure host arithmetic (bit-compatible with the reference) -----------------------------------
+// reference src/renderer.cpp:135-150
+Renderer::ScreenBasis Renderer::ComputeScreenBasis(const Camera &cam, unsigned width, unsigned height) {
+    const float aspect = (float)width / height;
+    // cam.Up projected onto the plane orthogonal to cam.Dir
+    const Vec3f up = ((cam.Dir ^ cam.Up) ^ cam.Dir).normalized();
+    const Vec3f target = cam.Pos + cam.Dir.normalized() * cam.ScreenDist;
+    // screen centre -> right edge, then centre -> top edge
+    const Vec3f a = (cam.Dir.normalized() ^ up) * cam.ScreenDist * aspect * std::tan(cam.FovY / 2 * GPUART_PI / 180);
+    const Vec3f b = up * a.length() / aspect;
+    ScreenBasis s;
+    s.Pos = cam.Pos;
+    s.BottomLeft = target - a - b;
+    s.DeltaHorz = 2 * a;
+    s.DeltaVert = 2 * b;
+    return s;
+}
+
+// reference src/renderer.cpp:573-574
+float Renderer::ComputePixelSize(const Camera &cam, unsigned height) {
+    return 2 * cam.ScreenDist * std::tan(cam.FovY / 2 * GPUART_PI / 180) / height;
+}
+
+// reference src/renderer.h:175-179
+Vec3f Renderer::ComputeSunDirection(float azimuth, float altitude) {
+    return Vec3f(1, 0, 0).vroty(-altitude).vrotz(azimuth);
+}
+
+// ---- lifecycle ----------------------------------------------------------------------------------
+Renderer::Renderer(unsigned viewportWidth, unsigned viewportHeight, const Camera &camera, int device) {
+    // defaults of the reference constructor (src/renderer.cpp:202-214)
+    Lighting.azimuth = GPUART_PI;
+    Lighting.altitude = GPUART_PI / 4;
+    Lighting.directLightingEnabled = true;
+    UserSphere.pos = Vec3f(0, 0, 0);
+    UserSphere.emittance = 0;
+    UserSphere.radius = 0;
+    UserSphere.flags = 0;
+    PathTracing.pathsPerPixel = 5;
+    PathTracing.pathsPerPass = PathTracing.pathsPerPixel;
+    PathTracing.numPathsRendered = 0;
+    CurrentCamera = camera;
+
+    if (!Check(gpuart_hip_create(device, &Backend), "creating the device back end")) return;
+    if (viewportWidth == 0 || viewportHeight == 0) {
+        std::cerr << "Renderer: viewport must not be empty." << std::endl;
+        return;
+    }
+    IsOK = true;  // UpdateViewportSize reports through IsOK
+    UpdateViewportSize(viewportWidth, viewportHeight);
+}
+
+Renderer::~Renderer() {
+    if (Backend) gpuart_hip_destroy(Backend);
+}
+
+bool Renderer::Check(int status, const char *what) {
+    if (status == 0) return true;
+    std::cerr << "Renderer: error " << status << " while " << what << ": " << gpuart_hip_last_error() << std::endl;
+    return false;
+}
+
+bool Renderer::UpdateViewportSize(unsigned width, unsigned height) {
+    if (!Backend || width == 0 || height == 0) return IsOK = false;
+    Viewport.width = width;
+    Viewport.height = height;
+    if (!Check(gpuart_hip_resize(Backend, width, height), "allocating per-pixel buffers")) return IsOK = false;
+    if (!SetCamera(CurrentCamera)) IsOK = false;
+    return IsOK;
+}
+
+bool Renderer::SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h) {
+    if (!Backend) return false;
+    if (!Check(gpuart_hip_set_tile(Backend, x0, y0, w, h), "setting the tile")) return false;
+    ResetPathTracing();
+    return true;
+}
+
+bool Renderer::SetCamera(const Camera &cam) {
+    CurrentCamera = cam;
+    if (!Backend) return false;
+    const ScreenBasis s = ComputeScreenBasis(cam, Viewport.width, Viewport.height);
+    float pos[3], bl[3], dh[3], dv[3];
+    s.Pos.storeIn(pos); s.BottomLeft.storeIn(bl); s.DeltaHorz.storeIn(dh); s.DeltaVert.storeIn(dv);
+    if (!Check(gpuart_hip_set_camera(Backend, pos, bl, dh, dv), "setting the camera")) return false;
+    ResetPathTracing();
+    return true;
+}
+
+// ---- scene --------------------------------------------------------------------------------------
+namespace {
+struct ByteCount {
+    size_t count;
+};
+std::ostream &operator<<(std::ostream &os, const ByteCount &bc) {
+    static const char *unit[] = {" B", " KiB", " MiB", " GiB"};
+    double v = (double)bc.count;
+    int u = 0;
+    while (v >= 1024 && u < 3) { v /= 1024; u++; }
+    return os << std::fixed << std::setprecision(u ? 1 : 0) << v << unit[u];
+}
+}  // namespace
+
+void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInfo) {
+    auto t0 = std::chrono::high_resolution_clock::now();
+    if (printInfo) std::cout << "Constructing BVH tree of " << primitives.size() << " primitives... " << std::flush;
+    Tree = BoundingVolumesHierarchy(primitives, 1024, 2);  // reference src/renderer.cpp:454
+    if (printInfo) {
+        std::cout << "done (" << Utils::TimeElapsed(t0) << ")." << std::endl;
+        std::cout << "Compiling BVH tree... " << std::flush;
+        t0 = std::chrono::high_resolution_clock::now();
+    }
+    Primitive::Data compiled;
+    Tree.Compile(compiled);
+    if (printInfo) std::cout << "done (" << Utils::TimeElapsed(t0) << ").\n";
+    if (!Backend || !Check(gpuart_hip_upload_bvh(Backend, compiled.data(), compiled.size() / RGBA_ELEMS), "uploading the BVH"))
+        IsOK = false;
+    if (printInfo) std::cout << "Compiled tree occupies " << ByteCount{compiled.size() * sizeof(float)} << "." << std::endl;
+    ResetPathTracing();
+}
+
+// ---- lighting / user sphere ---------------------------------------------------------------------
+void Renderer::SetUserSphere(const Vec3f &pos, float radius, float emittance) {
+    UserSphere.pos = pos;
+    UserSphere.radius = radius;
+    SetUserSphereEmittance(emittance);
+}
+
+void Renderer::SetUserSphereEmittance(float em) {
+    UserSphere.emittance = em;
+    SetFlag(EM_NONZERO, em > 0);
+}
+
+void Renderer::SetFlag(uint32_t flag, bool on) {
+    if (on) UserSphere.flags |= flag;
+    else UserSphere.flags &= ~flag;
+    ResetPathTracing();
+}
+
+gpuart_params Renderer::MakeParams() const {
+    gpuart_params p{};
+    const Vec3f sun = ComputeSunDirection(Lighting.azimuth, Lighting.altitude);
+    p.sunDirAlt[0] = sun.x; p.sunDirAlt[1] = sun.y; p.sunDirAlt[2] = sun.z; p.sunDirAlt[3] = Lighting.altitude;
+    p.sunEnabled = Lighting.directLightingEnabled ? 1 : 0;
+    p.userSphere[0] = UserSphere.pos.x; p.userSphere[1] = UserSphere.pos.y; p.userSphere[2] = UserSphere.pos.z;
+    p.userSphere[3] = UserSphere.radius;
+    const Vec3f em = Vec3f(1, 1, 1) * UserSphere.emittance;
+    p.userSphereEm[0] = em.x; p.userSphereEm[1] = em.y; p.userSphereEm[2] = em.z;
+    p.userSphereFlags = UserSphere.flags;
+    p.pixelSize = ComputePixelSize(CurrentCamera, Viewport.height);
+    p.cameraPos[0] = CurrentCamera.Pos.x; p.cameraPos[1] = CurrentCamera.Pos.y; p.cameraPos[2] = CurrentCamera.Pos.z;
+    p.maxSegments = (int32_t)MaxPathSegments;
+    p.minWeight = MinWeight;
+    return p;
+}
+
+// ---- rendering ----------------------------------------------------------------------------------
+void Renderer::RenderDirectLighting() {
+    if (!IsOK) return;
+    const gpuart_params p = MakeParams();
+    Check(gpuart_hip_render_direct(Backend, &p), "rendering direct lighting");
+}
+
+void Renderer::ResetPathTracing() {
+    PathTracing.numPathsRendered = 0;
+    if (Backend && Viewport.width) gpuart_hip_pt_reset(Backend);
+}
+
+void Renderer::RestartPathTracing(unsigned pathsPerPass, unsigned pathsPerPixel) {
+    PathTracing.pathsPerPixel = pathsPerPixel;
+    PathTracing.pathsPerPass = std::min(pathsPerPass, pathsPerPixel);
+    ResetPathTracing();
+}
+
+unsigned Renderer::RenderPathTracingPass() {
+    if (!IsOK) return PathTracing.numPathsRendered;
+    if (PathTracing.numPathsRendered < PathTracing.pathsPerPixel) {
+        const unsigned pathsToRender =
+            std::min(PathTracing.pathsPerPass, PathTracing.pathsPerPixel - PathTracing.numPathsRendered);
+        const gpuart_params p = MakeParams();
+        // RandSeed: four draws per pass from the never re-seeded generator (reference src/renderer.cpp:585-589)
+        std::uniform_real_distribution<float> distr(0, 1);
+        float seed[4];
+        for (float &s : seed) s = distr(RndGen);
+        if (Check(gpuart_hip_pt_pass(Backend, &p, seed, (int)pathsToRender), "rendering a path-tracing pass"))
+            PathTracing.numPathsRendered += pathsToRender;
+    }
+    return PathTracing.numPathsRendered;
+}
+
+bool Renderer::ReadDirectLighting(float *rgba) {
+    return IsOK && Check(gpuart_hip_read(Backend, 0, rgba, 1.0f), "reading the frame");
+}
+
+bool Renderer::ReadRadiance(float *rgba, bool normalized) {
+    // the division is the reference's ptracingNormalize program (shaders/pt_normalize.glsl:44-47)
+    const float div = normalized && PathTracing.numPathsRendered ? (float)PathTracing.numPathsRendered : 1.0f;
+    return IsOK && Check(gpuart_hip_read(Backend, 1, rgba, div), "reading the radiance accumulator");
+}
+
+bool Renderer::Finish() { return Backend && Check(gpuart_hip_finish(Backend), "waiting for the device"); }
+
+}  // namespace gpuart

@@ -1,0 +1,148 @@
+/* gpuart_hip.h — C ABI of libgpuart_hip.so, the MI355X (gfx950) device back end of gpuart.
+ *
+ * Drop-in boundary: this library replaces the reference's OpenGL wrapper layer
+ * (reference src/gl_utils.h:108-379 — GL::Buffer/Texture/Shader/Program/Framebuffer and
+ * GL::Utils::DrawFullscreenQuad) together with the GLSL programs the reference's Renderer
+ * launches through it (reference src/renderer.cpp:259-359). The C++ `gpuart::Renderer`
+ * (gpuart_amd/csrc/host/renderer.{h,cpp}) keeps the reference's public API and calls only the
+ * functions below; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes, no C++ types, no exceptions across the boundary.
+ * Every function returns 0 on success or a negative gpuart_hip_status; the message of the last
+ * failure (per thread) is available from gpuart_hip_last_error(). One context per device;
+ * contexts are independent. Host buffers are caller-owned. Work is asynchronous on the
+ * context's own HIP stream until gpuart_hip_finish() / a read-back.
+ *
+ * Image convention (as the reference's full-screen quad): row 0 is the BOTTOM row; pixels are
+ * RGBA32F; a context renders only its tile [x0,x0+tw) x [y0,y0+th) of the W x H frame and its
+ * buffers are tile-sized.
+ */
+#ifndef GPUART_HIP_H
+#define GPUART_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpuart_hip_ctx gpuart_hip_ctx;
+
+typedef enum gpuart_hip_status {
+    GPUART_HIP_OK = 0,
+    GPUART_HIP_ERR_ARG = -1,      /* bad argument / call order (e.g. render before upload) */
+    GPUART_HIP_ERR_DEVICE = -2,   /* a HIP runtime call failed */
+    GPUART_HIP_ERR_NO_DEVICE = -3 /* no usable gfx950 device */
+} gpuart_hip_status;
+
+/* The uniforms of the reference's directLighting / pathTracing programs
+ * (reference src/renderer.cpp:51-79,383-398,567-589; shaders/path_tracing.glsl:82-108). */
+typedef struct gpuart_params {
+    float sunDirAlt[4];       /* SunDirAlt: unit direction towards the Sun, altitude (rad) */
+    int32_t sunEnabled;       /* SunDirectLightingEnabled */
+    float userSphere[4];      /* UserSphere: centre, radius (radius 0 = disabled) */
+    float userSphereEm[3];    /* UserSphereEm */
+    uint32_t userSphereFlags; /* UserSphereFlags: 1 = EM_NONZERO, 2 = SPECULAR, 4 = FUZZY */
+    float pixelSize;          /* PixelSize */
+    float cameraPos[3];       /* CameraPos */
+    int32_t maxSegments;      /* MAX_PATH_SEGMENTS, a shader const (5) in the reference */
+    float minWeight;          /* MIN_WEIGHT, a shader const (0.01) in the reference */
+} gpuart_params;
+
+/* Exact work counters (closest-hit queries as the reference performs them). */
+typedef struct gpuart_counters {
+    uint64_t rays;          /* closest-hit BVH queries: camera, bounce and shadow rays */
+    uint64_t nodes;         /* distinct BVH nodes whose box was tested, summed over rays */
+    uint64_t prim_tests[4]; /* tested primitives by type: sphere, disc, triangle, cone */
+    uint64_t segments;      /* path segments traced */
+} gpuart_counters;
+
+const char *gpuart_hip_last_error(void);
+
+/* Replaces GL::Init + the Renderer constructor's shader/program creation
+ * (reference src/gl_utils.cpp:133-155, src/renderer.cpp:217-359). */
+int gpuart_hip_create(int device, gpuart_hip_ctx **out);
+int gpuart_hip_destroy(gpuart_hip_ctx *ctx);
+
+/* Replaces Renderer::InitPerPixelTextures (reference src/renderer.cpp:169-194): frame size and
+ * the tile this context owns (default: the whole frame). Clears the accumulator. */
+int gpuart_hip_resize(gpuart_hip_ctx *ctx, uint32_t width, uint32_t height);
+int gpuart_hip_set_tile(gpuart_hip_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t tw, uint32_t th);
+
+/* Replaces the GL_TEXTURE_BUFFER upload of Renderer::SetPrimitives (reference
+ * src/renderer.cpp:472-475). `quads` is the reference's canonical compiled tree
+ * (BoundingVolumesHierarchy::Compile, reference src/bvh.cpp:161-222), nquads RGBA32F quads;
+ * it is re-laid out on upload into the flat SoA device arrays described in DESIGN.md. */
+int gpuart_hip_upload_bvh(gpuart_hip_ctx *ctx, const float *quads, size_t nquads);
+
+/* Replaces the cameraInit program (reference shaders/cam_init.glsl:45-50, launched from
+ * Renderer::SetCamera, src/renderer.cpp:151-161): stores Pos/BottomLeft/DeltaHorz/DeltaVert;
+ * primary rays are regenerated in-kernel instead of being written to two ray textures. */
+int gpuart_hip_set_camera(gpuart_hip_ctx *ctx, const float pos[3], const float bottomLeft[3],
+                          const float deltaHorz[3], const float deltaVert[3]);
+
+/* Replaces the directLighting draw (reference src/renderer.cpp:372-404,
+ * shaders/direct_lighting.glsl:134-207). Result in the context's frame buffer. */
+int gpuart_hip_render_direct(gpuart_hip_ctx *ctx, const gpuart_params *p);
+
+/* Replaces the accumulator clear of Renderer::ResetPathTracing (reference src/renderer.cpp:490-500). */
+int gpuart_hip_pt_reset(gpuart_hip_ctx *ctx);
+
+/* Replaces one pathTracing draw (reference src/renderer.cpp:534-599,
+ * shaders/path_tracing.glsl:133-256): accum += radiance of `npaths` paths per pixel. */
+int gpuart_hip_pt_pass(gpuart_hip_ctx *ctx, const gpuart_params *p, const float randSeed[4], int npaths);
+
+/* Read-back (the reference draws to the GL framebuffer instead; ptracingNormalize,
+ * reference shaders/pt_normalize.glsl:44-47, is the `divide_by` of the accumulator).
+ * which: 0 = direct-lighting frame, 1 = path-tracing accumulator. divide_by <= 0 means 1.
+ * rgba_host receives tw*th*4 floats. Synchronises the stream. */
+int gpuart_hip_read(gpuart_hip_ctx *ctx, int which, float *rgba_host, float divide_by);
+
+/* Same, device to device, into caller-owned device memory (for the multi-GPU gather: the caller
+ * hands it to RCCL). Asynchronous on the context's stream; call gpuart_hip_finish before use. */
+int gpuart_hip_export(gpuart_hip_ctx *ctx, int which, void *rgba_device, float divide_by);
+
+/* glFinish() equivalent (reference src/main.cpp:564,584). */
+int gpuart_hip_finish(gpuart_hip_ctx *ctx);
+
+/* Traversal mode. 0 (default): fast path (LDS stack traversal; Sun shadow rays stop at the first
+ * accepted hit — results identical to the reference). 1: "reference work" mode —
+ * every query is a full closest-hit query in the reference's visiting order, with exact
+ * counters enabled (gpuart_hip_counters). */
+int gpuart_hip_set_mode(gpuart_hip_ctx *ctx, int reference_work);
+int gpuart_hip_counters(gpuart_hip_ctx *ctx, gpuart_counters *out, int reset);
+
+/* HIP-event timing of the render kernels launched since the last reset (events are recorded on
+ * the context's stream around each direct / pt_pass kernel). */
+int gpuart_hip_kernel_time(gpuart_hip_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
+
+/* Scene statistics after upload: node count, primitive count, tree depth, device bytes. */
+int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims, uint32_t *max_depth,
+                          uint64_t *device_bytes);
+
+/* ---- device-function test hooks (parity tests call the device code through these) ----------
+ * Arrays are n x 4 float32 in host memory. Each mirrors one reference GLSL function. */
+int gpuart_hip_test_random(gpuart_hip_ctx *ctx, const float *in, int n, float *out);
+int gpuart_hip_test_math(gpuart_hip_ctx *ctx, const float *in, int n, float *out); /* sin, cos, pow(y,16), sqrt(y) */
+int gpuart_hip_test_hemisphere(gpuart_hip_ctx *ctx, const float *v, const float *ri, int n, float *out);
+int gpuart_hip_test_inside_cone(gpuart_hip_ctx *ctx, const float *v, const float *normal, const float *ri,
+                                float halfAngle, int n, float *out);
+int gpuart_hip_test_sky(gpuart_hip_ctx *ctx, const float *dir, const float sunDirAlt[4], int n, float *out);
+/* Intersectors: `quads` = n canonical primitive payloads (StoreDataIntoBVH layout, 4 quads per
+ * primitive, unused quads ignored); out0 = (pos, P), out1 = (N, 0), zeros after pos on a miss. */
+int gpuart_hip_test_intersect(gpuart_hip_ctx *ctx, int ptype, const float *rs, const float *rd, const float *quads,
+                              int n, float *out0, float *out1);
+int gpuart_hip_test_aabb(gpuart_hip_ctx *ctx, const float *rs, const float *rd, const float *bmin, const float *bmax,
+                         int n, float *out);
+/* Closest-hit query over the uploaded tree incl. the user sphere; out0 = (pos, P), out1 = (N, type
+ * (+0.5 if the user sphere was hit), or -1 on a miss). any_hit != 0: out0[0] = 1/0 only. */
+int gpuart_hip_test_traverse(gpuart_hip_ctx *ctx, const float *rs, const float *rd, const float userSphere[4], int n,
+                             int any_hit, float *out0, float *out1);
+/* Camera rays of the context's tile: rstart / rdir, tw*th*4 floats each. */
+int gpuart_hip_test_cam_rays(gpuart_hip_ctx *ctx, float *rstart, float *rdir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUART_HIP_H */

@@ -1,6 +1,8 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md). Never linked into the product.
 // C ABI over the CPU restatement, for ctypes (tests/, __graft_entry__.smoke(), bench.py's
 // cpu_baseline leg). Arrays are (n,4) float32 unless stated otherwise.
+#include <xmmintrin.h>
+
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -19,13 +21,21 @@ inline void out4(float *o, int i, float a, float b, float c, float d) {
     o[4 * i] = a; o[4 * i + 1] = b; o[4 * i + 2] = c; o[4 * i + 3] = d;
 }
 
+// llvmpipe runs shaders with denormals flushed (FTZ + DAZ): `1e-40f * 2` is 0 there [probed].
+// Every entry point and worker thread of the restatement runs under the same MXCSR mode.
+struct FtzDaz {
+    unsigned saved;
+    FtzDaz() : saved(_mm_getcsr()) { _mm_setcsr(saved | 0x8040u); }
+    ~FtzDaz() { _mm_setcsr(saved); }
+};
+
 template <class F>
 void parallel_rows(int rows, int nthreads, F f) {
-    if (nthreads <= 1) { for (int r = 0; r < rows; r++) f(r, 0); return; }
+    if (nthreads <= 1) { FtzDaz g; for (int r = 0; r < rows; r++) f(r, 0); return; }
     std::atomic<int> next{0};
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++)
-        th.emplace_back([&, t] { for (int r; (r = next.fetch_add(1)) < rows;) f(r, t); });
+        th.emplace_back([&, t] { FtzDaz g; for (int r; (r = next.fetch_add(1)) < rows;) f(r, t); });
     for (auto &t : th) t.join();
 }
 }  // namespace
@@ -38,27 +48,33 @@ struct orc_stats {
 
 // ---- per-function batch evaluators ---------------------------------------------------------
 void orc_random(const float *in, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         V4 v = in4(in, i);
         out4(out, i, random1(v.x), random2(v.x, v.y), random3(V3{v.x, v.y, v.z}), random4(v));
     }
 }
 void orc_sincos(const float *in, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) { float s, c; sincos_lp(in[4 * i], &s, &c); out4(out, i, s, c, 0, 0); }
 }
 void orc_pow16(const float *in, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) out4(out, i, pow_lp(in[4 * i], 16.0f), 0, 0, 0);
 }
 void orc_hemisphere(const float *v, const float *ri, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) { V3 r = GetRandomHemisphereDirection(in3(v, i), in3(ri, i)); out4(out, i, r.x, r.y, r.z, 0); }
 }
 void orc_inside_cone(const float *v, const float *nrm, const float *ri, float halfAngle, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         V3 r = GetRandomDirectionInsideCone(in3(v, i), in3(nrm, i), halfAngle, in3(ri, i));
         out4(out, i, r.x, r.y, r.z, 0);
     }
 }
 void orc_sky(const float *dir, const float *sunDirAlt, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) { V3 r = GetSkyColor(in3(dir, i), sunDirAlt); out4(out, i, r.x, r.y, r.z, 0); }
 }
 // out0 = (pos, P), out1 = (N, 0); P,N zeroed on a miss (undefined in the reference).
@@ -67,6 +83,7 @@ static void store_hit(float pos, V3 p, V3 nn, int i, float *o0, float *o1) {
     else { out4(o0, i, pos, 0, 0, 0); out4(o1, i, 0, 0, 0, 0); }
 }
 void orc_sphere(const float *rs, const float *rd, const float *sph, int n, float *o0, float *o1) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         float pos; V3 p{0, 0, 0}, nn{0, 0, 0}; V4 s = in4(sph, i);
         SphereIntersection(in3(rs, i), in3(rd, i), V3{s.x, s.y, s.z}, s.w, pos, p, nn);
@@ -74,6 +91,7 @@ void orc_sphere(const float *rs, const float *rd, const float *sph, int n, float
     }
 }
 void orc_disc(const float *rs, const float *rd, const float *cr, const float *dn, int n, float *o0, float *o1) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         float pos; V3 p{0, 0, 0}, nn{0, 0, 0}; V4 c = in4(cr, i);
         DiscIntersection(in3(rs, i), in3(rd, i), V3{c.x, c.y, c.z}, c.w, in3(dn, i), pos, p, nn);
@@ -82,6 +100,7 @@ void orc_disc(const float *rs, const float *rd, const float *cr, const float *dn
 }
 void orc_triangle(const float *rs, const float *rd, const float *v0, const float *v1, const float *v2, int n, float *o0,
                   float *o1) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         float pos; V3 p{0, 0, 0}, nn{0, 0, 0};
         TriangleIntersection(in3(rs, i), in3(rd, i), in3(v0, i), in3(v1, i), in3(v2, i), pos, p, nn);
@@ -90,6 +109,7 @@ void orc_triangle(const float *rs, const float *rd, const float *v0, const float
 }
 void orc_cone(const float *rs, const float *rd, const float *q0, const float *q1, const float *q2, const float *q3, int n,
               float *o0, float *o1) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         float pos; V3 p{0, 0, 0}, nn{0, 0, 0}; V4 prm = in4(q3, i);
         ConeIntersection(in3(rs, i), in3(rd, i), in4(q0, i), in4(q1, i), in4(q2, i), prm.x, prm.y, prm.z, pos, p, nn);
@@ -98,6 +118,7 @@ void orc_cone(const float *rs, const float *rd, const float *q0, const float *q1
 }
 /// AABB test against a 2-quad box per sample; out = (hit?1:0, pos)
 void orc_aabb(const float *rs, const float *rd, const float *bmin, const float *bmax, int n, float *out) {
+    FtzDaz ftz_guard;
     for (int i = 0; i < n; i++) {
         float box[8] = {bmin[4 * i], bmin[4 * i + 1], bmin[4 * i + 2], 0, bmax[4 * i], bmax[4 * i + 1], bmax[4 * i + 2], 0};
         V3 d = in3(rd, i); V3 rdiv{1 / d.x, 1 / d.y, 1 / d.z};
@@ -108,6 +129,7 @@ void orc_aabb(const float *rs, const float *rd, const float *bmin, const float *
 /// Closest-hit query (optionally incl. user sphere); o0=(pos,P) o1=(N,type) ; type -1 on miss.
 void orc_traverse(const float *tree, const float *rs, const float *rd, const float *userSphere, int n, float *o0,
                   float *o1, orc_stats *stats) {
+    FtzDaz ftz_guard;
     TravStats st;
     for (int i = 0; i < n; i++) {
         Hit h; h.p = V3{0, 0, 0}; h.n = V3{0, 0, 0};
@@ -155,6 +177,7 @@ void orc_randseeds(uint32_t seed, int npasses, float *out) {
 // ---- frames ----------------------------------------------------------------------------------
 /// cam = 12 floats from orc_camera. Image rows bottom-up (row 0 = bottom), RGBA32F, tile-local.
 void orc_cam_rays(const float *cam, int W, int H, float *rstart, float *rdir) {
+    FtzDaz ftz_guard;
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             V3 s, d;
@@ -166,6 +189,7 @@ void orc_cam_rays(const float *cam, int W, int H, float *rstart, float *rdir) {
 
 /// UV of selected pixels: xy = n x (int x, int y); out = n x 2 floats.
 void orc_pixel_uv(const int *xy, int n, int W, int H, float *out) {
+    FtzDaz ftz_guard;
     float coef[12];
     QuadUVCoefs(W, H, coef);
     for (int i = 0; i < n; i++) PixelUV(xy[2 * i], xy[2 * i + 1], W, H, coef, out[2 * i], out[2 * i + 1]);

@@ -1,0 +1,142 @@
+"""CPU-only tests of the product's host side: the C++ Renderer/Scene library (libgpuart.so) against the
+oracle's host restatement, the loaders, and the C-ABI surface of libgpuart_hip.so (load + exports only —
+no compute calls without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gpuart_amd import binding as B
+from gpuart_amd import synth_scenes as S
+from oracle import oracle as O
+from tests.util import assert_bits, scene
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    L = B.hip_lib()
+    hdr = open(os.path.join(ROOT, "include", "gpuart_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(gpuart_hip_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libgpuart_hip.so does not export " + n
+
+
+def test_host_c_api_exports():
+    L = B.host_lib()
+    hdr = open(os.path.join(ROOT, "gpuart_amd", "csrc", "host", "capi.h")).read()
+    for n in sorted(set(re.findall(r"\b(gpuart_[a-z_0-9]+)\s*\(", hdr))):
+        assert hasattr(L, n), n
+
+
+def test_product_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(B.HipError):
+        B.Backend(0)
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    with pytest.raises(B.HipError):
+        B.Renderer(64, 64, cam)
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (no CPU fallback)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gpuart_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|liboracle", src, re.M), f
+
+
+@pytest.mark.parametrize("name", ["box", "scene_pc", "scene_p", "scene_d"])
+def test_bvh_bytes_equal_oracle(name):
+    prims = scene(name)
+    a, da = B.compile_bvh(prims)
+    b, db = O.build_bvh(prims)
+    assert da == db and a.shape == b.shape
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("levels,minprims", [(1024, 1), (1024, 4), (3, 2), (1, 2)])
+def test_bvh_build_parameters(levels, minprims):
+    prims = scene("scene_pc")
+    a, _ = B.compile_bvh(prims, levels, minprims)
+    b, _ = O.build_bvh(prims, levels, minprims)
+    assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_bvh_ties_and_duplicates():
+    """Equal box centres exercise std::sort's unstable order; both sides must agree byte for byte."""
+    rng = np.random.RandomState(9)
+    prims = []
+    for i in range(300):
+        c = np.round(rng.uniform(-1, 1, 3) * 4) / 4  # coarse grid -> many identical centres
+        prims.append((S.SPHERE, [float(c[0]), float(c[1]), float(c[2]), 0.1]))
+    prims += prims[:50]
+    a, _ = B.compile_bvh(prims)
+    b, _ = O.build_bvh(prims)
+    assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (1920, 1080), (3840, 2160), (7680, 4320), (37, 23)])
+@pytest.mark.parametrize("camsel", ["default", "bench"])
+def test_camera_basis_and_pixel_size(W, H, camsel):
+    cam = dict(S.DEFAULT_CAMERA if camsel == "default" else S.BENCH_CAMERA)
+    cam["dir"] = S.camera_dir(cam)
+    a = B.camera_basis(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    b = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    assert_bits(a, b, "screen basis")
+
+
+def test_sun_direction():
+    for az, alt in [(S.SUN_AZIMUTH, S.SUN_ALTITUDE), (0.3, 0.1), (5.0, 1.5)]:
+        assert_bits(B.sun_direction(az, alt), O.sun_direction(az, alt), "sun direction")
+
+
+def test_ply_loader_round_trip(tmp_path):
+    """Scene D written as ASCII PLY and loaded through LoadMeshFromPLY (x10, translated) compiles to the same
+    tree as the in-memory mesh."""
+    model, faces = S.dragon_class_mesh(32, 24)
+    path = str(tmp_path / "mesh.ply")
+    S.write_ply(path, model, faces)
+    disc = (S.DISC, [0, 0, 0, 0, 0, 1, 5])
+    a, _, nloaded = B.compile_bvh_from_file("ply", path, 10.0, (0, 0, -0.5), [disc])
+    assert nloaded == len(faces)
+    w = S.load_transform(model)
+    prims = [(S.TRIANGLE, row.tolist()) for row in w[faces].reshape(-1, 9)] + [disc]
+    b, _ = O.build_bvh(prims)
+    assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_ply_loader_rejects_bad_files(tmp_path):
+    p = tmp_path / "bad.ply"
+    p.write_text("plx\n")
+    with pytest.raises(RuntimeError):
+        B.compile_bvh_from_file("ply", str(p))
+    p.write_text("ply\nelement vertex 3\nelement face 1\nend_header\n0 0 0\n1 0 0\n0 1 0\n4 0 1 2 2\n")
+    with pytest.raises(RuntimeError):
+        B.compile_bvh_from_file("ply", str(p))  # non-triangular face
+    p.write_text("ply\nelement vertex 3\nelement face 1\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n")
+    with pytest.raises(RuntimeError):
+        B.compile_bvh_from_file("ply", str(p))  # vertex index out of range
+    with pytest.raises(RuntimeError):
+        B.compile_bvh_from_file("ply", str(tmp_path / "missing.ply"))
+
+
+def test_primitive_list_loader(tmp_path):
+    """'sphere x y z [r]' / 'cone ...' dialect (src/utils.cpp:168-197), default radius 4, '#' comments."""
+    p = tmp_path / "prims.dat"
+    p.write_text("# comment\nsphere 1 2 3 0.5\nsphere -1 0 2\n\ncone 0 0 0 0 0 1 0.3 0.1\nsphere 4 4 4 1\n")
+    mag, tr = 0.25, (0.0, 0.0, 1.0)
+    a, _, n = B.compile_bvh_from_file("dat", str(p), mag, tr)
+    assert n == 4
+    f = np.float32
+    def T(v): return [float(f(tr[k]) + f(mag) * f(v[k])) for k in range(3)]
+    prims = [(S.SPHERE, T([1, 2, 3]) + [float(f(mag) * f(0.5))]), (S.SPHERE, T([-1, 0, 2]) + [float(f(mag) * f(4.0))]),
+             (S.CONE, T([0, 0, 0]) + T([0, 0, 1]) + [float(f(mag) * f(0.3)), float(f(mag) * f(0.1))]),
+             (S.SPHERE, T([4, 4, 4]) + [float(f(mag) * f(1.0))])]
+    b, _ = O.build_bvh(prims)
+    assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
