@@ -213,18 +213,25 @@ class Backend:
     def finish(self):
         self._chk(self.L.gpuart_hip_finish(self.ctx))
 
-    def set_mode(self, reference_work):
-        self._chk(self.L.gpuart_hip_set_mode(self.ctx, C.c_int(1 if reference_work else 0)))
+    MODE_WAVEFRONT, MODE_REFERENCE_WORK, MODE_MEGAKERNEL = 0, 1, 2
+
+    def set_mode(self, mode):
+        """0 wavefront (fast, default), 1 reference-work (exact counters), 2 megakernel."""
+        self._chk(self.L.gpuart_hip_set_mode(self.ctx, C.c_int(int(mode))))
+
+    def set_timing(self, level):
+        self._chk(self.L.gpuart_hip_set_timing(self.ctx, C.c_int(int(level))))
 
     def counters(self, reset=False):
         c = Counters()
         self._chk(self.L.gpuart_hip_counters(self.ctx, C.byref(c), C.c_int(1 if reset else 0)))
         return c
 
-    def kernel_time(self, reset=False):
+    def kernel_time(self, cls=0, reset=False):
+        """(total ms, count) of HIP-event-timed intervals: cls 0 = render calls, 1 = BVH-query kernels."""
         ms = C.c_double(0)
         n = C.c_uint64(0)
-        self._chk(self.L.gpuart_hip_kernel_time(self.ctx, C.byref(ms), C.byref(n), C.c_int(1 if reset else 0)))
+        self._chk(self.L.gpuart_hip_kernel_time(self.ctx, C.c_int(cls), C.byref(ms), C.byref(n), C.c_int(1 if reset else 0)))
         return ms.value, n.value
 
     def scene_info(self):

@@ -11,8 +11,6 @@
 //             triangle { v0.xyz, T }{ e1.xyz, 0 }{ e2.xyz, 0 }     e1 = v1-v0, e2 = v2-v0 (fp32)
 //             cone     { c1.xyz, T }{ axis.xyz, len }{ r1, widthCoeff, cosB, dotAxC1 }
 //           T = bits(type)
-//   parent: uint32[N] = parent ordinal | bit31 "is lower child" (only used by the stackless
-//           fallback for trees deeper than the LDS stack).
 #pragma once
 #include "device_math.h"
 
@@ -27,7 +25,6 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 struct Scene {
     const float4 *__restrict__ nodes;
     const float4 *__restrict__ prims;
-    const uint32_t *__restrict__ parent;
     uint32_t num_nodes;
     uint32_t max_depth;
 };
@@ -211,84 +208,120 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, uint32_t cou
     return false;
 }
 
-/// Closest-hit query, LDS-stack form. Visits exactly the nodes, in exactly the order, of the
+// ---- traversal stack: short per-lane ring in LDS + spill to global memory -------------------------
+// Entry = (upper-child ordinal, parent's box-entry parameter). Entries [base, sp) live in the LDS ring
+// (slot = index % RING, one column per lane -> conflict-free 8-byte accesses); entries [0, base) live in
+// a per-lane global spill column. The oldest entries (closest to the root, popped last) are the ones
+// spilled, so spills are rare; any tree depth up to the reference's 1024 levels works without a
+// separate code path.
+#define GD_RING 16
+
+struct TravStack {
+    uint2 *ring;             ///< LDS, [GD_RING][BLOCK] ; this lane's column is ring[slot * BLOCK]
+    uint2 *spill;            ///< global, [levels][total_lanes]; this lane's column is spill[level * stride]
+    uint32_t ring_stride;    ///< BLOCK
+    uint32_t spill_stride;   ///< total lanes of the launch
+    uint32_t sp, base;
+    GD_FN void reset() { sp = 0; base = 0; }
+    GD_FN void push(uint2 e) {
+        if (sp - base == GD_RING) {
+            spill[(size_t)base * spill_stride] = ring[(base & (GD_RING - 1)) * ring_stride];
+            base++;
+        }
+        ring[(sp & (GD_RING - 1)) * ring_stride] = e;
+        sp++;
+    }
+    GD_FN uint2 pop() {  // precondition: sp > 0
+        if (sp == base) {
+            base--;
+            ring[(base & (GD_RING - 1)) * ring_stride] = spill[(size_t)base * spill_stride];
+        }
+        sp--;
+        return ring[(sp & (GD_RING - 1)) * ring_stride];
+    }
+};
+
+/// Traversal state of one ray. The walk visits exactly the nodes, in exactly the order, of the
 /// reference's stackless parent-pointer walk (shaders/bvh_intersection.glsl:360-457): lower child
-/// first, prune on `entry > closest`, and — where the reference re-tests a parent's box when it
-/// returns from the lower child — the parent's entry parameter kept on the stack is compared with
-/// the current closest hit instead (same value, since the test is a pure function of node and ray).
-/// Stack entries: (hi-child ordinal, parent entry parameter), one column per lane.
-template <bool ANY_HIT, bool COUNT, int STACK_DEPTH, int BLOCK>
-GD_FN void traverse_stack(const Scene &sc, const Ray &r, uint2 (*stack)[BLOCK], int lane, float &closest,
-                          uint32_t &hit_prim, WorkCounters *wc) {
-    F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
-    closest = 1e+19f;
-    hit_prim = GD_NO_PRIM;
-    uint32_t node = 0;
-    int sp = 0;
-    if (COUNT) wc->rays++;
+/// first, prune on `entry > closest`; where the reference re-tests a parent's box when it returns
+/// from the lower child, the parent's entry parameter kept on the stack is compared with the current
+/// closest hit instead (same value: the test is a pure function of node and ray).
+enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2 };
+
+struct Trav {
+    float closest;
+    uint32_t hit_prim;
+    uint32_t node;       ///< DESCEND: node to test; LEAF: first primitive index
+    uint32_t leaf_count; ///< LEAF: number of primitives
+    int state;
+};
+
+GD_FN void trav_init(Trav &t, TravStack &st) {
+    t.closest = 1e+19f;
+    t.hit_prim = GD_NO_PRIM;
+    t.node = 0;
+    t.leaf_count = 0;
+    t.state = TRAV_DESCEND;
+    st.reset();
+}
+
+/// Returns to the nearest pending upper child that is still worth visiting (or finishes).
+GD_FN void trav_pop(Trav &t, TravStack &st) {
     for (;;) {
-        float4 n0 = sc.nodes[2 * node], n1 = sc.nodes[2 * node + 1];
-        if (COUNT) wc->nodes++;
-        float entry;
-        bool hit = aabb_entry(r, rdiv, xyz(n0), xyz(n1), entry);
-        if (hit && !(entry > closest)) {
-            uint32_t meta = __float_as_uint(n1.w), link = __float_as_uint(n0.w);
-            if (meta & GD_META_LEAF) {
-                if (leaf_test<ANY_HIT, COUNT>(sc, r, link, meta & ~GD_META_LEAF, closest, hit_prim, wc) && ANY_HIT) return;
-            } else {
-                stack[sp++][lane] = make_uint2(link, __float_as_uint(entry));
-                node = node + 1;
-                continue;
-            }
-        }
-        // return towards the root until a pending upper child is still worth visiting
-        for (;;) {
-            if (sp == 0) return;
-            uint2 e = stack[--sp][lane];
-            if (__uint_as_float(e.y) > closest) continue;
-            node = e.x;
-            break;
-        }
+        if (st.sp == 0) { t.state = TRAV_DONE; return; }
+        uint2 e = st.pop();
+        if (__uint_as_float(e.y) > t.closest) continue;  // the reference's parent re-test
+        t.node = e.x;
+        t.state = TRAV_DESCEND;
+        return;
     }
 }
 
-/// The same query as a literal parent-pointer walk (no stack), for trees deeper than the LDS stack.
-template <bool ANY_HIT, bool COUNT>
-GD_FN void traverse_stackless(const Scene &sc, const Ray &r, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
-    F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
-    closest = 1e+19f;
-    hit_prim = GD_NO_PRIM;
-    uint32_t node = 0;
-    bool returning = false;
-    int from = 0;  // 0 none, 1 lower, 2 upper
-    if (COUNT) wc->rays++;
-    for (;;) {
-        if (returning && from == 2 && node == 0) return;
-        float4 n0 = sc.nodes[2 * node], n1 = sc.nodes[2 * node + 1];
+/// One node visit: box test, then descend / mark leaf / pop. Precondition: state == DESCEND.
+template <bool COUNT>
+GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc) {
+    float4 n0 = sc.nodes[2 * t.node], n1 = sc.nodes[2 * t.node + 1];
+    if (COUNT) wc->nodes++;
+    float entry;
+    bool hit = aabb_entry(r, rdiv, xyz(n0), xyz(n1), entry);
+    if (hit && !(entry > t.closest)) {
         uint32_t meta = __float_as_uint(n1.w), link = __float_as_uint(n0.w);
-        if (COUNT && !returning) wc->nodes++;
-        float entry;
-        if (aabb_entry(r, rdiv, xyz(n0), xyz(n1), entry)) {
-            if (entry > closest)
-                returning = true;
-            else if (meta & GD_META_LEAF) {
-                if (leaf_test<ANY_HIT, COUNT>(sc, r, link, meta & ~GD_META_LEAF, closest, hit_prim, wc) && ANY_HIT) return;
-                returning = true;
-            } else {
-                returning = false;
-                if (from == 0) node = node + 1;
-                else if (from == 1) { from = 0; node = link; }
-                else returning = true;
-            }
-        } else
-            returning = true;
-        if (returning) {
-            uint32_t pw = sc.parent[node];
-            from = (pw & 0x80000000u) ? 1 : 2;
-            if (node == 0) from = 2;
-            node = pw & 0x7fffffffu;
+        if (meta & GD_META_LEAF) {
+            t.node = link;
+            t.leaf_count = meta & ~GD_META_LEAF;
+            t.state = TRAV_LEAF;
+        } else {
+            st.push(make_uint2(link, __float_as_uint(entry)));
+            t.node = t.node + 1;
         }
+        return;
     }
+    trav_pop(t, st);
+}
+
+/// Tests the primitives of the pending leaf, then pops. Precondition: state == LEAF.
+template <bool ANY_HIT, bool COUNT>
+GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
+    if (leaf_test<ANY_HIT, COUNT>(sc, r, t.node, t.leaf_count, t.closest, t.hit_prim, wc) && ANY_HIT) {
+        t.state = TRAV_DONE;
+        return;
+    }
+    trav_pop(t, st);
+}
+
+/// Runs one query to completion (megakernels and test hooks).
+template <bool ANY_HIT, bool COUNT>
+GD_FN void traverse(const Scene &sc, const Ray &r, TravStack &st, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+    F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    Trav t;
+    trav_init(t, st);
+    if (COUNT) wc->rays++;
+    while (t.state != TRAV_DONE) {
+        if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, r, rdiv, t, st, wc);
+        else trav_step_leaf<ANY_HIT, COUNT>(sc, r, t, st, wc);
+    }
+    closest = t.closest;
+    hit_prim = t.hit_prim;
 }
 
 /// Recomputes point, normal and type of the winning primitive (pure function of ray + record).

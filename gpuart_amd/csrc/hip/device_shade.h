@@ -105,25 +105,27 @@ GD_FN F3 lambert(F3 lightDir, F3 normal, F3 diffuse) {
     return f3(0, 0, 0);
 }
 
-/// A closest-hit (or, when ANY, first-hit) BVH query dispatching to the stack / stackless walk.
-template <bool ANY, bool COUNT, bool STACKLESS, int STACK_DEPTH, int BLOCK>
-GD_FN void bvh_query(const Scene &sc, const Ray &r, uint2 (*stack)[BLOCK], int lane, float &closest, uint32_t &prim,
-                     WorkCounters *wc) {
-    if (STACKLESS) traverse_stackless<ANY, COUNT>(sc, r, closest, prim, wc);
-    else traverse_stack<ANY, COUNT, STACK_DEPTH, BLOCK>(sc, r, stack, lane, closest, prim, wc);
+/// Whether the Sun is visible from a shadow query's result: nothing in the BVH was hit and the user
+/// sphere does not occlude either (reference CheckIntersectionInclUserSphere, intersection.glsl:98).
+GD_FN bool sun_visible(const gpuart_params &P, F3 origin, F3 sun, uint32_t shadow_prim) {
+    if (shadow_prim != GD_NO_PRIM) return false;
+    Ray sr; sr.o = origin; sr.d = sun;
+    float usPos; F3 a, b;
+    sphere_hit(sr, f3(P.userSphere[0], P.userSphere[1], P.userSphere[2]), P.userSphere[3], usPos, a, b);
+    return !(usPos > GD_VISIBILITY_OFFSET);
 }
 
-// ---- reference shaders/direct_lighting.glsl:134-207 ------------------------------------------
-template <bool REFWORK, bool STACKLESS, int STACK_DEPTH, int BLOCK>
-GD_FN F3 direct_lighting_pixel(const Scene &sc, const gpuart_params &P, F3 rstart, F3 rdir, uint2 (*stack)[BLOCK],
-                               int lane, WorkCounters *wc) {
+// ---- reference shaders/direct_lighting.glsl:134-207 (whole pixel in one thread) ----------------------
+template <bool REFWORK>
+GD_FN F3 direct_lighting_pixel(const Scene &sc, const gpuart_params &P, F3 rstart, F3 rdir, TravStack &st,
+                               WorkCounters *wc) {
     const float AMBIENT = 0.15f;
     F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     F3 cw = f3(1, 1, 1), out = f3(0, 0, 0);
     for (int i = 0; i <= 1; i++) {
         Ray r; r.o = rstart; r.d = rdir;
         float closest; uint32_t prim; Surface h; bool ush;
-        bvh_query<false, REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, r, stack, lane, closest, prim, wc);
+        traverse<false, REFWORK>(sc, r, st, closest, prim, wc);
         resolve_hit(sc, r, closest, prim, P.userSphere, h, ush);
         if ((P.userSphereFlags & 2u) && ush) {
             rstart = h.p;
@@ -137,21 +139,15 @@ GD_FN F3 direct_lighting_pixel(const Scene &sc, const gpuart_params &P, F3 rstar
                 if (P.sunEnabled == 1) {
                     Ray sr; sr.o = h.p; sr.d = sun;
                     float sc_closest; uint32_t sprim;
-                    bvh_query<!REFWORK, REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, sr, stack, lane, sc_closest, sprim, wc);
-                    bool lit = (sprim == GD_NO_PRIM);
-                    if (lit) {  // the user sphere can still occlude (intersection.glsl:98)
-                        float usPos; F3 a, b;
-                        sphere_hit(sr, f3(P.userSphere[0], P.userSphere[1], P.userSphere[2]), P.userSphere[3], usPos, a, b);
-                        lit = !(usPos > GD_VISIBILITY_OFFSET);
-                    }
-                    if (lit) out = out + lambert(sun, h.n, diffuse);
+                    traverse<!REFWORK, REFWORK>(sc, sr, st, sc_closest, sprim, wc);
+                    if (sun_visible(P, h.p, sun, sprim)) out = out + lambert(sun, h.n, diffuse);
                 }
                 if (P.userSphereFlags & 1u) {
                     F3 dts = f3(P.userSphere[0], P.userSphere[1], P.userSphere[2]) - h.p;
                     float dist = length3(dts);
                     Ray er; er.o = h.p; er.d = f3(dts.x / dist, dts.y / dist, dts.z / dist);
                     float ec; uint32_t eprim;
-                    bvh_query<false, REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, er, stack, lane, ec, eprim, wc);
+                    traverse<false, REFWORK>(sc, er, st, ec, eprim, wc);
                     if (eprim == GD_NO_PRIM || ec > dist) {
                         F3 l = lambert(er.d, h.n, diffuse);
                         float d2 = dot3(dts, dts);  // dist*dist: NIR folds sqrt(a)*sqrt(a) to |a|
@@ -168,78 +164,122 @@ GD_FN F3 direct_lighting_pixel(const Scene &sc, const gpuart_params &P, F3 rstar
     return out;
 }
 
-// ---- reference shaders/path_tracing.glsl:133-256 ---------------------------------------------
-template <bool REFWORK, bool STACKLESS, int STACK_DEPTH, int BLOCK>
-GD_FN F3 path_tracing_pixel(const Scene &sc, const gpuart_params &P, float4 seed, int npaths, F3 rstart0, F3 rdir0,
-                            uint2 (*stack)[BLOCK], int lane, WorkCounters *wc, uint32_t &segments) {
-    const float FUZZY_ANGLE = 10 * 3.14159f / 180;
-    F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
-    F3 seed3 = f3(seed.x, seed.y, seed.z);
-    F3 cam = f3(P.cameraPos[0], P.cameraPos[1], P.cameraPos[2]);
-    F3 usc = f3(P.userSphere[0], P.userSphere[1], P.userSphere[2]);
+// ---- reference shaders/path_tracing.glsl:133-256, split at its two BVH queries ---------------------------
+// The per-path state between queries (what the GLSL keeps in registers across loop iterations):
+//   ray (rstart, rdir) of the next/current segment, colorWeight, pathColor, segment counter i.
+// path_begin  : lines 154-175  (jitter, first ray)
+// path_shade  : lines 182-233  (after the closest-hit query of a segment)
+// path_sun    : lines 234-245  (after the Sun shadow query)
+// path_finish : lines 247-252  (after the segment loop)
+
+/// First ray of path j of a pixel (path_tracing.glsl:141-170).
+GD_FN void path_begin(const gpuart_params &P, float4 seed, int j, F3 rstart0, F3 rdir0, F3 &rstart, F3 &rdir) {
     F3 o1;
     if (fabsf(rdir0.x) > 1.0e-5f || fabsf(rdir0.y) > 1.0e-5f) o1 = normalize3(f3(rdir0.y, -rdir0.x, 0));
     else o1 = normalize3(f3(0, -rdir0.z, rdir0.y));
     F3 o2 = cross3(normalize3(rdir0), o1);
+    float rand1 = random1(seed.x + (float)j);
+    float rand2 = random1(seed.y + (float)j);
+    rstart = (rstart0 + ((rand1 - 0.5f) * o1) * P.pixelSize) + ((rand2 - 0.5f) * o2) * P.pixelSize;
+    rdir = rstart - f3(P.cameraPos[0], P.cameraPos[1], P.cameraPos[2]);
+}
+
+enum { PATH_ENDED = 0, PATH_CONTINUES = 1 };
+
+/// Outcome of shading one segment.
+struct ShadeResult {
+    int next;          ///< PATH_ENDED / PATH_CONTINUES (another segment follows)
+    bool broke;        ///< the GLSL loop was left by `break` (sky or emissive sphere)
+    bool want_shadow;  ///< the reference runs a Sun shadow query from `rstart` here
+    bool sun_matters;  ///< ... and its result can change pathColor (dot(sun, n) > 0)
+    F3 sun_term;       ///< dot(sun, n) * albedo, to be added to pathColor if the Sun is visible
+    bool ush, specular;
+};
+
+/// path_tracing.glsl:182-233 for segment i (0-based), given the finished closest-hit query of ray r.
+GD_FN ShadeResult path_shade(const Scene &sc, const gpuart_params &P, float4 seed, int i, const Ray &r, float closest,
+                             uint32_t prim, F3 &rstart, F3 &rdir, F3 &cw, F3 &pathColor) {
+    const float FUZZY_ANGLE = 10 * 3.14159f / 180;
+    ShadeResult o;
+    o.next = PATH_ENDED; o.broke = false; o.want_shadow = false; o.sun_matters = false; o.sun_term = f3(0, 0, 0); o.specular = false;
+    Surface h;
+    resolve_hit(sc, r, closest, prim, P.userSphere, h, o.ush);
+    int ptype = h.ptype;
+    if (o.ush) {
+        if (P.userSphereFlags & 1u) {
+            pathColor = pathColor + f3(P.userSphereEm[0], P.userSphereEm[1], P.userSphereEm[2]) * cw;
+            o.broke = true;
+            return o;
+        }
+        ptype = P_SPHERE;
+    } else if (ptype == -1) {
+        pathColor = pathColor + (2.0f * sky_color(r.d, P.sunDirAlt)) * cw;
+        o.broke = true;
+        return o;
+    }
+    F3 albedo = primitive_color(ptype);
+    cw = cw * albedo;
+    rstart = h.p;
+    F3 seed3 = f3(seed.x, seed.y, seed.z);
+    if (o.ush && (P.userSphereFlags & 2u)) {
+        if (!(P.userSphereFlags & 4u)) rdir = reflect3(r.d, h.n);
+        else rdir = random_direction_inside_cone(reflect3(r.d, h.n), h.n, FUZZY_ANGLE, h.p + seed3);
+        o.specular = true;
+    } else {
+        rdir = random_hemisphere_direction(h.n, h.p + seed3);
+    }
+    if (P.sunEnabled == 1 && !o.specular) {
+        float dotp = dot3(f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]), h.n);
+        // The reference issues the shadow query unconditionally; when dotp <= 0 its result cannot
+        // change pathColor, so the fast mode skips it (sun_matters); reference-work mode still runs it.
+        o.want_shadow = true;
+        o.sun_matters = dotp > 0;
+        o.sun_term = o.sun_matters ? dotp * albedo : f3(0, 0, 0);
+    }
+    // loop header of the next iteration (path_tracing.glsl:177)
+    if (i + 1 < P.maxSegments && (cw.x > P.minWeight && cw.y > P.minWeight && cw.z > P.minWeight)) o.next = PATH_CONTINUES;
+    return o;
+}
+
+/// path_tracing.glsl:247-252: value added to the pixel's colour when a path ends.
+/// `i` = value of the GLSL loop counter when the loop was left.
+GD_FN F3 path_finish(const gpuart_params &P, F3 rdir0, int i, bool ush, bool specular, F3 pathColor) {
+    if (i == 0 && !ush) return sky_color(rdir0, P.sunDirAlt);
+    if (i == 0 && ush && !specular) return f3(1, 1, 1);
+    return pathColor;
+}
+
+// ---- the same loop in one thread (megakernel form; kept as an independent cross-check / ablation) ----
+template <bool REFWORK>
+GD_FN F3 path_tracing_pixel(const Scene &sc, const gpuart_params &P, float4 seed, int npaths, F3 rstart0, F3 rdir0,
+                            TravStack &st, WorkCounters *wc, uint32_t &segments) {
+    F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     F3 color = f3(0, 0, 0);
     for (int j = 0; j < npaths; j++) {
-        float rand1 = random1(seed.x + (float)j);
-        float rand2 = random1(seed.y + (float)j);
-        F3 rstart = (rstart0 + ((rand1 - 0.5f) * o1) * P.pixelSize) + ((rand2 - 0.5f) * o2) * P.pixelSize;
-        F3 rdir = rstart - cam;
+        F3 rstart, rdir;
+        path_begin(P, seed, j, rstart0, rdir0, rstart, rdir);
         F3 pathColor = f3(0, 0, 0), cw = f3(1, 1, 1);
         bool ush = false, specular = false;
-        int i;
-        for (i = 0; i < P.maxSegments && (cw.x > P.minWeight && cw.y > P.minWeight && cw.z > P.minWeight); i++) {
-            Ray r; r.o = rstart; r.d = rdir;
-            float closest; uint32_t prim; Surface h;
-            bvh_query<false, REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, r, stack, lane, closest, prim, wc);
-            resolve_hit(sc, r, closest, prim, P.userSphere, h, ush);
-            segments++;
-            int ptype = h.ptype;
-            if (ush) {
-                if (P.userSphereFlags & 1u) {
-                    pathColor = pathColor + f3(P.userSphereEm[0], P.userSphereEm[1], P.userSphereEm[2]) * cw;
-                    break;
+        int i = 0;
+        if (P.maxSegments > 0 && 1.0f > P.minWeight)
+            for (;;) {
+                Ray r; r.o = rstart; r.d = rdir;
+                float closest; uint32_t prim;
+                traverse<false, REFWORK>(sc, r, st, closest, prim, wc);
+                segments++;
+                ShadeResult s = path_shade(sc, P, seed, i, r, closest, prim, rstart, rdir, cw, pathColor);
+                ush = s.ush; specular = s.specular;
+                if (s.broke) break;
+                if (s.want_shadow && (REFWORK || s.sun_matters)) {
+                    Ray sr; sr.o = rstart; sr.d = sun;
+                    float sclosest; uint32_t sprim;
+                    traverse<!REFWORK, REFWORK>(sc, sr, st, sclosest, sprim, wc);
+                    if (sun_visible(P, rstart, sun, sprim)) pathColor = pathColor + s.sun_term;
                 }
-                ptype = P_SPHERE;
-            } else if (ptype == -1) {
-                pathColor = pathColor + (2.0f * sky_color(rdir, P.sunDirAlt)) * cw;
-                break;
+                i++;
+                if (s.next != PATH_CONTINUES) break;
             }
-            F3 albedo = primitive_color(ptype);
-            cw = cw * albedo;
-            rstart = h.p;
-            if (ush && (P.userSphereFlags & 2u)) {
-                if (!(P.userSphereFlags & 4u)) rdir = reflect3(rdir, h.n);
-                else rdir = random_direction_inside_cone(reflect3(rdir, h.n), h.n, FUZZY_ANGLE, h.p + seed3);
-                specular = true;
-            } else {
-                rdir = random_hemisphere_direction(h.n, h.p + seed3);
-                specular = false;
-            }
-            if (P.sunEnabled == 1 && !specular) {
-                // Sun shadow ray. The reference runs a full closest-hit query and uses only
-                // "nothing hit" (path_tracing.glsl:229-245); stopping at the first accepted hit
-                // gives the same answer. REFWORK keeps the full query so the counters see it.
-                Ray sr; sr.o = h.p; sr.d = sun;
-                float sclosest; uint32_t sprim;
-                bvh_query<!REFWORK, REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, sr, stack, lane, sclosest, sprim, wc);
-                bool lit = (sprim == GD_NO_PRIM);
-                if (lit) {
-                    float usPos; F3 a, b;
-                    sphere_hit(sr, usc, P.userSphere[3], usPos, a, b);
-                    lit = !(usPos > GD_VISIBILITY_OFFSET);
-                }
-                if (lit) {
-                    float dotp = dot3(sun, h.n);
-                    if (dotp > 0) pathColor = pathColor + dotp * albedo;
-                }
-            }
-        }
-        if (i == 0 && !ush) pathColor = sky_color(rdir0, P.sunDirAlt);
-        else if (i == 0 && ush && !specular) pathColor = f3(1, 1, 1);
-        color = color + pathColor;
+        color = color + path_finish(P, rdir0, i, ush, specular, pathColor);
     }
     return color;
 }

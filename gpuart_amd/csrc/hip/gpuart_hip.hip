@@ -2,6 +2,8 @@
 // See include/gpuart_hip.h for the boundary and DESIGN.md for layout / kernel notes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -13,13 +15,33 @@
 
 using namespace gd;
 
-#define STACK_DEPTH 32
-#define BLOCK 64  // one wavefront per workgroup: an 8x8 pixel tile
+#define BLOCK 64          // one wavefront per workgroup
+#define FETCH_CHUNK 64    // rays a wave takes from a queue per atomic
+#define REFILL_LANES 16   // a traversal wave goes back for new rays once this many lanes are idle
+#define LEAF_LANES 12     // leaf (primitive) code runs once this many lanes wait at a leaf
 
 // =================================================================================================
 // Kernels
 // =================================================================================================
 namespace {
+
+/// Per-path state of the wavefront pipeline, one slot per pixel of the tile in 8x8-tile-major order
+/// (slot s: tile s/64, pixel s%64 inside it), all arrays SoA and 16-byte aligned.
+struct PathBuffers {
+    float4 *ray_o, *ray_d;   ///< ray of the current / next segment
+    uint2 *hit;              ///< closest-hit result of the current segment: (bits(t), primitive index)
+    float4 *cw;              ///< colorWeight
+    float4 *pc;              ///< pathColor
+    float4 *sun;             ///< pending Sun term (xyz), w = bits(1: the path ends after its shadow query)
+    float4 *color;           ///< colour of the earlier paths of this pass (NumPathsPerPixel > 1)
+    uint32_t *queue[2];      ///< slots that trace segment s (ping-pong)
+    uint32_t *shadow_queue;  ///< slots with a pending Sun shadow query
+    uint32_t *counters;      ///< per segment s: [4s] rays, [4s+1] fetch cursor, [4s+2] shadow rays, [4s+3] fetch cursor
+    uint32_t n_slots;
+};
+#define SLOT_INVALID 0xffffffffu
+
+GD_FN int lane_id() { return threadIdx.x & 63; }
 
 GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned long long *g) {
     // one atomic per counter per wavefront
@@ -27,48 +49,249 @@ GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned lo
     for (int k = 0; k < 7; k++) {
         unsigned long long s = v[k];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[k], s);
+        if (lane_id() == 0 && s) atomicAdd(&g[k], s);
     }
 }
 
-GD_FN bool tile_pixel(const Frame &f, uint32_t &lx, uint32_t &ly) {
-    // block -> 8x8 pixel tile, thread -> pixel inside it (row-major within the tile)
+/// slot -> pixel of the tile; false for the padding slots of ragged edge tiles.
+GD_FN bool slot_pixel(const Frame &f, uint32_t slot, uint32_t &lx, uint32_t &ly) {
     uint32_t tiles_x = (f.tw + 7) / 8;
-    uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    lx = bx * 8 + (threadIdx.x & 7);
-    ly = by * 8 + (threadIdx.x >> 3);
+    uint32_t t = slot >> 6, w = slot & 63;
+    lx = (t % tiles_x) * 8 + (w & 7);
+    ly = (t / tiles_x) * 8 + (w >> 3);
     return lx < f.tw && ly < f.th;
 }
 
-template <bool REFWORK, bool STACKLESS>
-__global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_params P, float4 *__restrict__ out,
-                                                  unsigned long long *counters) {
-    __shared__ uint2 stack[STACKLESS ? 1 : STACK_DEPTH][BLOCK];
-    uint32_t lx, ly;
-    bool active = tile_pixel(f, lx, ly);
+GD_FN TravStack make_stack(uint2 *ring, uint2 *spill, uint32_t total_lanes) {
+    TravStack st;
+    st.ring = ring + lane_id();
+    st.ring_stride = BLOCK;
+    st.spill = spill + (size_t)blockIdx.x * BLOCK + lane_id();
+    st.spill_stride = total_lanes;
+    st.reset();
+    return st;
+}
+
+/// Wave-aggregated append: lanes with `pred` get consecutive positions of `queue` (one atomic per wave).
+GD_FN void queue_push(uint32_t *queue, uint32_t *counter, bool pred, uint32_t value) {
+    unsigned long long m = __ballot(pred);
+    if (!m) return;
+    uint32_t base = 0;
+    int leader = __ffsll((long long)m) - 1;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1))] = value;
+}
+
+/// Adds a finished path's colour to its pixel (path_tracing.glsl:252,255): color += pathColor for every
+/// path of the pass, then accum = PrevRadiance + color.
+GD_FN void path_commit(const Frame &f, const PathBuffers &b, float4 *accum, uint32_t slot, int j, int npaths, F3 value) {
+    F3 c = (j == 0) ? f3(0.0f + value.x, 0.0f + value.y, 0.0f + value.z) : xyz(b.color[slot]) + value;
+    if (j == npaths - 1) {
+        uint32_t lx, ly;
+        slot_pixel(f, slot, lx, ly);
+        size_t idx = (size_t)ly * f.tw + lx;
+        float4 prev = accum[idx];
+        accum[idx] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
+    } else
+        b.color[slot] = make_float4(c.x, c.y, c.z, 0);
+}
+
+// ---- wavefront stage 0: first ray of path j of every pixel (path_tracing.glsl:141-175) ---------------
+__global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, float4 seed, int j, int npaths, PathBuffers b,
+                                               float4 *accum) {
+    const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < b.n_slots; slot += gridDim.x * BLOCK) {
+        uint32_t lx, ly;
+        bool valid = slot_pixel(f, slot, lx, ly);
+        uint32_t q = SLOT_INVALID;
+        if (valid) {
+            F3 rs0, rd0, rs, rd;
+            camera_ray(f, f.x0 + lx, f.y0 + ly, rs0, rd0);
+            if (no_segments) {  // the GLSL loop body never runs: i == 0 and no user-sphere hit
+                path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, 0, false, false, f3(0, 0, 0)));
+            } else {
+                path_begin(P, seed, j, rs0, rd0, rs, rd);
+                b.ray_o[slot] = make_float4(rs.x, rs.y, rs.z, 0);
+                b.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, 0);
+                b.cw[slot] = make_float4(1, 1, 1, 0);
+                b.pc[slot] = make_float4(0, 0, 0, 0);
+                q = slot;
+            }
+        }
+        b.queue[0][slot] = q;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.counters[0] = no_segments ? 0u : b.n_slots;
+}
+
+// ---- wavefront stage 1/3: BVH queries for a whole queue, persistent waves with lane refill -----------
+// SHADOW = false: closest-hit query of segment `seg` for every slot of queue[seg&1]; result -> hit[slot].
+// SHADOW = true : Sun shadow query for every slot of shadow_queue; applies the Sun term and, for paths
+//                 that end with this segment, commits the path.
+// A lane that finishes its ray takes the next one from the queue (wave-local chunk, one atomic per
+// FETCH_CHUNK rays), so all 64 lanes keep traversing; box tests and leaf tests are issued as separate
+// wave-wide phases (leaf code waits until LEAF_LANES lanes need it).
+template <bool SHADOW, bool ANY, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
+                                                 int npaths, float4 *accum, uint2 *spill, unsigned long long *gcounters) {
+    __shared__ uint2 ring[GD_RING * BLOCK];
+    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+    const uint32_t *queue = SHADOW ? b.shadow_queue : b.queue[seg & 1];
+    const uint32_t n = b.counters[4 * seg + (SHADOW ? 2 : 0)];
+    uint32_t *cursor = &b.counters[4 * seg + (SHADOW ? 3 : 1)];
+    const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     WorkCounters wc = {0, 0, {0, 0, 0, 0}};
-    if (active) {
+
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool exhausted = false;                  // wave-uniform
+    uint32_t slot = SLOT_INVALID;
+    Ray r; r.o = f3(0, 0, 0); r.d = f3(1, 0, 0);
+    F3 rdiv = f3(1, 1, 1);
+    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.leaf_count = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the queue
+        unsigned long long idle = __ballot(slot == SLOT_INVALID);
+        while (idle && !exhausted) {
+            if (chunk_next == chunk_end) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(cursor, (uint32_t)FETCH_CHUNK);
+                base = __shfl(base, 0, 64);
+                if (base >= n) { exhausted = true; break; }
+                chunk_next = base;
+                chunk_end = min(base + (uint32_t)FETCH_CHUNK, n);
+            }
+            uint32_t want = (uint32_t)__popcll(idle), take = min(want, chunk_end - chunk_next);
+            uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1));
+            if (slot == SLOT_INVALID && rank < take) {
+                uint32_t s = queue[chunk_next + rank];
+                if (s != SLOT_INVALID) {
+                    slot = s;
+                    r.o = xyz(b.ray_o[s]);
+                    r.d = SHADOW ? sun : xyz(b.ray_d[s]);
+                    rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+                    trav_init(t, st);
+                    if (COUNT) wc.rays++;
+                }
+            }
+            chunk_next += take;
+            idle = __ballot(slot == SLOT_INVALID);
+            if (take == want) break;
+        }
+        if (__ballot(slot != SLOT_INVALID) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- traverse until enough lanes have finished
+        for (;;) {
+            if (slot != SLOT_INVALID && t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, r, rdiv, t, st, COUNT ? &wc : nullptr);
+            unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && t.state == TRAV_LEAF);
+            unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
+            if (at_leaf && ((uint32_t)__popcll(at_leaf) >= LEAF_LANES || !descending)) {
+                if (slot != SLOT_INVALID && t.state == TRAV_LEAF) trav_step_leaf<ANY, COUNT>(sc, r, t, st, COUNT ? &wc : nullptr);
+                descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
+                at_leaf = __ballot(slot != SLOT_INVALID && t.state == TRAV_LEAF);
+            }
+            unsigned long long busy = descending | at_leaf;
+            if (!busy) break;
+            if (!exhausted && 64u - (uint32_t)__popcll(busy) >= REFILL_LANES) break;
+        }
+        // ---- retire finished rays
+        if (slot != SLOT_INVALID && t.state == TRAV_DONE) {
+            if (!SHADOW) {
+                b.hit[slot] = make_uint2(__float_as_uint(t.closest), t.hit_prim);
+            } else {
+                float4 term = b.sun[slot];
+                F3 pathColor = xyz(b.pc[slot]);
+                if (sun_visible(P, r.o, sun, t.hit_prim)) pathColor = pathColor + xyz(term);
+                if (__float_as_uint(term.w) & 1u) path_commit(f, b, accum, slot, j, npaths, pathColor);
+                else b.pc[slot] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
+            }
+            slot = SLOT_INVALID;
+        }
+    }
+    if (COUNT) flush_counters(wc, 0, gcounters);
+}
+
+// ---- wavefront stage 2: shade segment `seg` of every path in queue[seg&1] (path_tracing.glsl:182-233) ---
+template <bool REFWORK>
+__global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_params P, float4 seed, PathBuffers b, int seg,
+                                                 int j, int npaths, float4 *accum, unsigned long long *gcounters) {
+    const uint32_t n = b.counters[4 * seg];
+    const uint32_t *queue = b.queue[seg & 1];
+    uint32_t *next_queue = b.queue[(seg + 1) & 1];
+    uint32_t segments = 0;
+    const uint32_t rounds = (n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+    for (uint32_t k = 0; k < rounds; k++) {
+        uint32_t e = (k * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+        uint32_t slot = e < n ? queue[e] : SLOT_INVALID;
+        bool go_on = false, shadow = false;
+        if (slot != SLOT_INVALID) {
+            Ray r; r.o = xyz(b.ray_o[slot]); r.d = xyz(b.ray_d[slot]);
+            uint2 h = b.hit[slot];
+            F3 cw = xyz(b.cw[slot]), pathColor = xyz(b.pc[slot]);
+            F3 rstart = r.o, rdir = r.d;
+            segments++;
+            ShadeResult s = path_shade(sc, P, seed, seg, r, __uint_as_float(h.x), h.y, rstart, rdir, cw, pathColor);
+            if (s.broke) {
+                uint32_t lx, ly; F3 rs0, rd0;
+                slot_pixel(f, slot, lx, ly);
+                camera_ray(f, f.x0 + lx, f.y0 + ly, rs0, rd0);
+                path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, seg, s.ush, s.specular, pathColor));
+            } else {
+                go_on = s.next == PATH_CONTINUES;
+                shadow = s.want_shadow && (REFWORK || s.sun_matters);
+                if (shadow)
+                    b.sun[slot] = make_float4(s.sun_term.x, s.sun_term.y, s.sun_term.z, __uint_as_float(go_on ? 0u : 1u));
+                if (go_on || shadow) b.ray_o[slot] = make_float4(rstart.x, rstart.y, rstart.z, 0);
+                if (go_on) {
+                    b.ray_d[slot] = make_float4(rdir.x, rdir.y, rdir.z, 0);
+                    b.cw[slot] = make_float4(cw.x, cw.y, cw.z, 0);
+                }
+                if (go_on || shadow) b.pc[slot] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
+                if (!go_on && !shadow) path_commit(f, b, accum, slot, j, npaths, pathColor);  // i >= 1: no special case
+            }
+        }
+        queue_push(next_queue, &b.counters[4 * (seg + 1)], go_on, slot);
+        queue_push(b.shadow_queue, &b.counters[4 * seg + 2], shadow, slot);
+    }
+    if (REFWORK) {
+        WorkCounters z = {0, 0, {0, 0, 0, 0}};
+        flush_counters(z, segments, gcounters);
+    }
+}
+
+// ---- megakernels: one thread per pixel, persistent grid over 8x8 tiles -------------------------------------
+template <bool REFWORK>
+__global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_params P, uint32_t n_slots, float4 *__restrict__ out,
+                                                  uint2 *spill, unsigned long long *counters) {
+    __shared__ uint2 ring[GD_RING * BLOCK];
+    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
+        uint32_t lx, ly;
+        if (!slot_pixel(f, slot, lx, ly)) continue;
         F3 rs, rd;
         camera_ray(f, f.x0 + lx, f.y0 + ly, rs, rd);
-        F3 c = direct_lighting_pixel<REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, P, rs, rd, stack, threadIdx.x, &wc);
+        F3 c = direct_lighting_pixel<REFWORK>(sc, P, rs, rd, st, &wc);
         out[(size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 1.0f);
     }
     if (REFWORK) flush_counters(wc, 0, counters);
 }
 
-template <bool REFWORK, bool STACKLESS>
-__global__ void __launch_bounds__(BLOCK) k_pt_pass(Scene sc, Frame f, gpuart_params P, float4 seed, int npaths,
-                                                   float4 *__restrict__ accum, unsigned long long *counters) {
-    __shared__ uint2 stack[STACKLESS ? 1 : STACK_DEPTH][BLOCK];
-    uint32_t lx, ly;
-    bool active = tile_pixel(f, lx, ly);
+template <bool REFWORK>
+__global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_params P, float4 seed, int npaths, uint32_t n_slots,
+                                                   float4 *__restrict__ accum, uint2 *spill, unsigned long long *counters) {
+    __shared__ uint2 ring[GD_RING * BLOCK];
+    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
     WorkCounters wc = {0, 0, {0, 0, 0, 0}};
     uint32_t segments = 0;
-    if (active) {
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
+        uint32_t lx, ly;
+        if (!slot_pixel(f, slot, lx, ly)) continue;
         F3 rs, rd;
         camera_ray(f, f.x0 + lx, f.y0 + ly, rs, rd);
-        F3 c = path_tracing_pixel<REFWORK, STACKLESS, STACK_DEPTH, BLOCK>(sc, P, seed, npaths, rs, rd, stack, threadIdx.x,
-                                                                          &wc, segments);
+        F3 c = path_tracing_pixel<REFWORK>(sc, P, seed, npaths, rs, rd, st, &wc, segments);
         size_t idx = (size_t)ly * f.tw + lx;
         float4 prev = accum[idx];
         accum[idx] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
@@ -135,29 +358,30 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
     bool h = aabb_entry(r, f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z), xyz(bmin[i]), xyz(bmax[i]), pos);
     out[i] = make_float4(h ? 1.0f : 0.0f, h ? pos : 0.0f, 0, 0);
 }
-template <bool ANY, bool STACKLESS>
+template <bool ANY>
 __global__ void __launch_bounds__(BLOCK) k_test_traverse(Scene sc, const float4 *rs, const float4 *rd, Float4Arg us, int n,
-                                                         float4 *o0, float4 *o1) {
-    __shared__ uint2 stack[STACKLESS ? 1 : STACK_DEPTH][BLOCK];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
-    float closest; uint32_t prim;
-    bvh_query<ANY, false, STACKLESS, STACK_DEPTH, BLOCK>(sc, r, stack, threadIdx.x, closest, prim, nullptr);
-    if (ANY) {
-        o0[i] = make_float4(prim != GD_NO_PRIM ? 1.0f : 0.0f, 0, 0, 0);
-        o1[i] = make_float4(0, 0, 0, 0);
-        return;
-    }
-    Surface h; h.p = f3(0, 0, 0); h.n = f3(0, 0, 0);
-    bool ush;
-    resolve_hit(sc, r, closest, prim, us.v, h, ush);
-    if (h.ptype >= 0) {
-        o0[i] = make_float4(h.pos, h.p.x, h.p.y, h.p.z);
-        o1[i] = make_float4(h.n.x, h.n.y, h.n.z, (float)h.ptype + (ush ? 0.5f : 0.0f));
-    } else {
-        o0[i] = make_float4(-1, 0, 0, 0);
-        o1[i] = make_float4(0, 0, 0, -1);
+                                                         float4 *o0, float4 *o1, uint2 *spill) {
+    __shared__ uint2 ring[GD_RING * BLOCK];
+    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
+        float closest; uint32_t prim;
+        traverse<ANY, false>(sc, r, st, closest, prim, nullptr);
+        if (ANY) {
+            o0[i] = make_float4(prim != GD_NO_PRIM ? 1.0f : 0.0f, 0, 0, 0);
+            o1[i] = make_float4(0, 0, 0, 0);
+            continue;
+        }
+        Surface h; h.p = f3(0, 0, 0); h.n = f3(0, 0, 0);
+        bool ush;
+        resolve_hit(sc, r, closest, prim, us.v, h, ush);
+        if (h.ptype >= 0) {
+            o0[i] = make_float4(h.pos, h.p.x, h.p.y, h.p.z);
+            o1[i] = make_float4(h.n.x, h.n.y, h.n.z, (float)h.ptype + (ush ? 0.5f : 0.0f));
+        } else {
+            o0[i] = make_float4(-1, 0, 0, 0);
+            o1[i] = make_float4(0, 0, 0, -1);
+        }
     }
 }
 __global__ void k_test_cam_rays(Frame f, float4 *rstart, float4 *rdir) {
@@ -208,6 +432,7 @@ void plane_coef(float x0, float y0, float x1, float y1, float x2, float y2, floa
 
 struct TimedLaunch {
     hipEvent_t start, stop;
+    int cls;  ///< 0: a whole render call (direct frame / path-tracing pass), 1: one BVH-query kernel
 };
 
 }  // namespace
@@ -218,16 +443,23 @@ struct gpuart_hip_ctx {
     Frame frame{};
     bool have_camera = false, have_scene = false;
     float4 *d_nodes = nullptr, *d_prims = nullptr;
-    uint32_t *d_parent = nullptr;
+    uint2 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow
+    uint32_t spill_levels = 0;
+    uint32_t num_cus = 256;
+    uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
+    PathBuffers pb{};              ///< wavefront path state (tile-sized)
+    void *d_pathmem = nullptr;
+    uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
     uint32_t max_depth = 0;
     float4 *d_direct = nullptr, *d_accum = nullptr;
     size_t tile_pixels = 0;
     unsigned long long *d_counters = nullptr;
-    int reference_work = 0;
+    int mode = 0;  ///< 0 wavefront (fast), 1 reference-work (wavefront, full queries, counters), 2 megakernel
     std::vector<TimedLaunch> pending, free_events;
-    double timed_ms = 0;
-    uint64_t timed_launches = 0;
+    double timed_ms[2] = {0, 0};
+    uint64_t timed_launches[2] = {0, 0};
+    int timing_level = 1;  ///< 0 none, 1 per render call, 2 also per BVH-query kernel
     float *d_scratch = nullptr;  // test hooks
     size_t scratch_bytes = 0;
 };
@@ -243,6 +475,45 @@ int realloc_tile(gpuart_hip_ctx *c) {
     HIP_TRY(hipMalloc(&c->d_accum, c->tile_pixels * sizeof(float4)));
     HIP_TRY(hipMemsetAsync(c->d_direct, 0, c->tile_pixels * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
+    // wavefront path state: one slot per pixel of the 8x8-tile-padded tile
+    if (c->d_pathmem) { (void)hipFree(c->d_pathmem); c->d_pathmem = nullptr; }
+    const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
+    const size_t n = tiles * 64;
+    if (n > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
+    const size_t bytes = n * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t));
+    HIP_TRY(hipMalloc(&c->d_pathmem, bytes));
+    char *m = (char *)c->d_pathmem;
+    PathBuffers &b = c->pb;
+    uint32_t *keep_counters = b.counters;
+    b.ray_o = (float4 *)m; m += n * sizeof(float4);
+    b.ray_d = (float4 *)m; m += n * sizeof(float4);
+    b.cw = (float4 *)m; m += n * sizeof(float4);
+    b.pc = (float4 *)m; m += n * sizeof(float4);
+    b.sun = (float4 *)m; m += n * sizeof(float4);
+    b.color = (float4 *)m; m += n * sizeof(float4);
+    b.hit = (uint2 *)m; m += n * sizeof(uint2);
+    b.queue[0] = (uint32_t *)m; m += n * sizeof(uint32_t);
+    b.queue[1] = (uint32_t *)m; m += n * sizeof(uint32_t);
+    b.shadow_queue = (uint32_t *)m;
+    b.counters = keep_counters;
+    b.n_slots = (uint32_t)n;
+    return 0;
+}
+
+int ensure_segment_counters(gpuart_hip_ctx *c, uint32_t nseg) {
+    if (c->pb.counters && c->counter_segments >= nseg) return 0;
+    if (c->pb.counters) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->pb.counters); c->pb.counters = nullptr; }
+    HIP_TRY(hipMalloc(&c->pb.counters, 4 * ((size_t)nseg + 1) * sizeof(uint32_t)));
+    c->counter_segments = nseg;
+    return 0;
+}
+
+int ensure_spill(gpuart_hip_ctx *c) {
+    const uint32_t levels = c->max_depth > GD_RING ? c->max_depth - GD_RING : 0;
+    if (c->d_spill && c->spill_levels >= levels) return 0;
+    if (c->d_spill) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_spill); c->d_spill = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_spill, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint2)));
+    c->spill_levels = levels;
     return 0;
 }
 
@@ -259,35 +530,37 @@ Scene scene_of(const gpuart_hip_ctx *c) {
     Scene s;
     s.nodes = c->d_nodes;
     s.prims = c->d_prims;
-    s.parent = c->d_parent;
     s.num_nodes = (uint32_t)c->n_nodes;
     s.max_depth = c->max_depth;
     return s;
 }
 
-bool stackless(const gpuart_hip_ctx *c) { return c->max_depth > STACK_DEPTH; }
 
 int fold_timings(gpuart_hip_ctx *c) {
     for (auto &t : c->pending) {
         HIP_TRY(hipEventSynchronize(t.stop));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
-        c->timed_ms += ms;
-        c->timed_launches++;
+        c->timed_ms[t.cls] += ms;
+        c->timed_launches[t.cls]++;
         c->free_events.push_back(t);
     }
     c->pending.clear();
     return 0;
 }
 
-int begin_timed(gpuart_hip_ctx *c, TimedLaunch &t) {
-    if (c->pending.size() >= 512) { int r = fold_timings(c); if (r) return r; }
-    if (!c->free_events.empty()) { t = c->free_events.back(); c->free_events.pop_back(); }
+int begin_timed(gpuart_hip_ctx *c, TimedLaunch &t, int cls) {
+    t.cls = cls;
+    t.start = t.stop = nullptr;
+    if (c->timing_level < 1) return 0;
+    if (c->pending.size() >= 4096) { int r = fold_timings(c); if (r) return r; }
+    if (!c->free_events.empty()) { t = c->free_events.back(); c->free_events.pop_back(); t.cls = cls; }
     else { HIP_TRY(hipEventCreate(&t.start)); HIP_TRY(hipEventCreate(&t.stop)); }
     HIP_TRY(hipEventRecord(t.start, c->stream));
     return 0;
 }
 int end_timed(gpuart_hip_ctx *c, TimedLaunch &t) {
+    if (!t.start) return 0;
     HIP_TRY(hipEventRecord(t.stop, c->stream));
     c->pending.push_back(t);
     return 0;
@@ -298,7 +571,6 @@ struct Converter {
     const float *q;
     size_t nq;
     std::vector<float4> nodes, prims;
-    std::vector<uint32_t> parent;
     uint32_t max_depth = 0;
     std::string err;
 
@@ -338,7 +610,7 @@ struct Converter {
         uint32_t flags = bits(b[8]);
         nodes.push_back(make_float4(b[0], b[1], b[2], 0));
         nodes.push_back(make_float4(b[4], b[5], b[6], 0));
-        parent.push_back(parentOrd | (isLower ? 0x80000000u : 0u));
+        (void)parentOrd; (void)isLower;
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
             uint32_t first = (uint32_t)(prims.size() / 3);
@@ -433,6 +705,8 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     gpuart_hip_ctx *c = new (std::nothrow) gpuart_hip_ctx();
     if (!c) return fail(GPUART_HIP_ERR_DEVICE, "out of host memory");
     c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    c->grid_waves = c->num_cus * 16;  // persistent grids: up to 16 one-wave workgroups per CU
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
@@ -448,7 +722,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_parent, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
+    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_pathmem, c->pb.counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -479,15 +753,14 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     Converter cv;
     cv.q = quads; cv.nq = nquads;
     if (!cv.node(0, 0, false, 0)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
-    cv.parent[0] = 0;
     int r;
     if ((r = upload_vec(c, c->d_nodes, cv.nodes))) return r;
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
-    if ((r = upload_vec(c, c->d_parent, cv.parent))) return r;
     c->n_nodes = cv.nodes.size() / 2;
     c->n_prims = cv.prims.size() / 3;
     c->max_depth = cv.max_depth;
-    c->scene_bytes = cv.nodes.size() * 16 + cv.prims.size() * 16 + cv.parent.size() * 4;
+    c->scene_bytes = cv.nodes.size() * 16 + cv.prims.size() * 16;
+    if ((r = ensure_spill(c))) return r;
     c->have_scene = true;
     return 0;
 }
@@ -512,18 +785,12 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
     int r = check_ready(c, p);
     if (r) return r;
     HIP_TRY(hipSetDevice(c->device));
-    dim3 grid(((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8));
+    dim3 grid(std::min<uint32_t>(c->grid_waves, c->pb.n_slots / BLOCK));
     Scene sc = scene_of(c);
     TimedLaunch t;
-    if ((r = begin_timed(c, t))) return r;
-    bool sl = stackless(c);
-    if (c->reference_work) {
-        if (sl) k_direct<true, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
-        else k_direct<true, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
-    } else {
-        if (sl) k_direct<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
-        else k_direct<false, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->d_direct, c->d_counters);
-    }
+    if ((r = begin_timed(c, t, 0))) return r;
+    if (c->mode == 1) k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->pb.n_slots, c->d_direct, c->d_spill, c->d_counters);
+    else k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->pb.n_slots, c->d_direct, c->d_spill, c->d_counters);
     HIP_TRY(hipGetLastError());
     return end_timed(c, t);
 }
@@ -535,25 +802,61 @@ int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
     return 0;
 }
 
+/// Upper bound on the number of segments any path can have: colorWeight's blue channel is multiplied by
+/// at most 0.35 per segment (path_tracing.glsl:123-126), and the loop stops once a channel is <= minWeight.
+static uint32_t segment_bound(const gpuart_params *p) {
+    if (p->maxSegments <= 0 || !(1.0f > p->minWeight)) return 0;
+    uint32_t n = (uint32_t)p->maxSegments;
+    if (p->minWeight > 0) {
+        double bound = std::ceil(std::log((double)p->minWeight) / std::log(0.36)) + 2;  // 0.36 > 0.35: safe side
+        if (bound < (double)n) n = (uint32_t)bound;
+    }
+    return n;
+}
+
 int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float randSeed[4], int npaths) {
     int r = check_ready(c, p);
     if (r) return r;
     if (!randSeed || npaths < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (npaths == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    dim3 grid(((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8));
     Scene sc = scene_of(c);
-    float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
+    const float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
+    const PathBuffers &b = c->pb;
     TimedLaunch t;
-    if ((r = begin_timed(c, t))) return r;
-    bool sl = stackless(c);
-    if (c->reference_work) {
-        if (sl) k_pt_pass<true, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
-        else k_pt_pass<true, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
-    } else {
-        if (sl) k_pt_pass<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
-        else k_pt_pass<false, false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->d_accum, c->d_counters);
+    if ((r = begin_timed(c, t, 0))) return r;
+    if (c->mode == 2) {  // megakernel: the whole path in one thread (ablation / cross-check)
+        dim3 grid(std::min<uint32_t>(c->grid_waves, b.n_slots / BLOCK));
+        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, b.n_slots, c->d_accum, c->d_spill, c->d_counters);
+        HIP_TRY(hipGetLastError());
+        return end_timed(c, t);
     }
-    HIP_TRY(hipGetLastError());
+    const uint32_t nseg = segment_bound(p);
+    if ((r = ensure_segment_counters(c, nseg))) return r;
+    const bool refwork = c->mode == 1;
+    const dim3 pgrid(c->grid_waves);
+    const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots / BLOCK));
+    for (int j = 0; j < npaths; j++) {
+        HIP_TRY(hipMemsetAsync(c->pb.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), c->stream));
+        k_gen<<<sgrid, BLOCK, 0, c->stream>>>(c->frame, *p, seed, j, npaths, b, c->d_accum);
+        for (uint32_t seg = 0; seg < nseg; seg++) {
+            TimedLaunch tt;
+            const bool detail = c->timing_level >= 2;
+            if (detail && (r = begin_timed(c, tt, 1))) return r;
+            if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
+            else k_trace<false, false, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
+            if (detail && (r = end_timed(c, tt))) return r;
+            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
+            else k_shade<false><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
+            if (p->sunEnabled == 1) {
+                if (detail && (r = begin_timed(c, tt, 1))) return r;
+                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
+                else k_trace<true, true, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
+                if (detail && (r = end_timed(c, tt))) return r;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+    }
     return end_timed(c, t);
 }
 
@@ -592,9 +895,15 @@ int gpuart_hip_finish(gpuart_hip_ctx *c) {
     return 0;
 }
 
-int gpuart_hip_set_mode(gpuart_hip_ctx *c, int reference_work) {
-    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
-    c->reference_work = reference_work ? 1 : 0;
+int gpuart_hip_set_mode(gpuart_hip_ctx *c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(GPUART_HIP_ERR_ARG, "bad mode");
+    c->mode = mode;
+    return 0;
+}
+
+int gpuart_hip_set_timing(gpuart_hip_ctx *c, int level) {
+    if (!c || level < 0 || level > 2) return fail(GPUART_HIP_ERR_ARG, "bad timing level");
+    c->timing_level = level;
     return 0;
 }
 
@@ -613,14 +922,14 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
     return 0;
 }
 
-int gpuart_hip_kernel_time(gpuart_hip_ctx *c, double *total_ms, uint64_t *launches, int reset) {
-    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+int gpuart_hip_kernel_time(gpuart_hip_ctx *c, int cls, double *total_ms, uint64_t *launches, int reset) {
+    if (!c || cls < 0 || cls > 1) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     int r = fold_timings(c);
     if (r) return r;
-    if (total_ms) *total_ms = c->timed_ms;
-    if (launches) *launches = c->timed_launches;
-    if (reset) { c->timed_ms = 0; c->timed_launches = 0; }
+    if (total_ms) *total_ms = c->timed_ms[cls];
+    if (launches) *launches = c->timed_launches[cls];
+    if (reset) { c->timed_ms[cls] = 0; c->timed_launches[cls] = 0; }
     return 0;
 }
 
@@ -681,17 +990,11 @@ int gpuart_hip_test_traverse(gpuart_hip_ctx *c, const float *rs, const float *rd
     if (!c || !c->have_scene || !us) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
     Float4Arg a; memcpy(a.v, us, 16);
     Scene sc = scene_of(c);
-    bool sl = stackless(c);
     const float *ins[] = {rs, rd}; float *outs[] = {out0, out1};
     return run_hook(c, n, ins, 2, outs, 2, [&](auto &i, auto &o) {
-        dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
-        if (any_hit) {
-            if (sl) k_test_traverse<true, true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
-            else k_test_traverse<true, false><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
-        } else {
-            if (sl) k_test_traverse<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
-            else k_test_traverse<false, false><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1]);
-        }
+        dim3 grid(std::min<uint32_t>(c->grid_waves, (uint32_t)((n + BLOCK - 1) / BLOCK)));
+        if (any_hit) k_test_traverse<true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1], c->d_spill);
+        else k_test_traverse<false><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1], c->d_spill);
     });
 }
 int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {

@@ -106,16 +106,21 @@ int gpuart_hip_export(gpuart_hip_ctx *ctx, int which, void *rgba_device, float d
 /* glFinish() equivalent (reference src/main.cpp:564,584). */
 int gpuart_hip_finish(gpuart_hip_ctx *ctx);
 
-/* Traversal mode. 0 (default): fast path (LDS stack traversal; Sun shadow rays stop at the first
- * accepted hit — results identical to the reference). 1: "reference work" mode —
- * every query is a full closest-hit query in the reference's visiting order, with exact
- * counters enabled (gpuart_hip_counters). */
-int gpuart_hip_set_mode(gpuart_hip_ctx *ctx, int reference_work);
+/* Execution mode of gpuart_hip_pt_pass / gpuart_hip_render_direct (images are identical in all modes):
+ *   0 (default) wavefront pipeline, fast: per segment a persistent BVH-query kernel, a shading kernel
+ *               and a Sun-shadow kernel that stops at the first accepted hit and is skipped for surfaces
+ *               facing away from the Sun;
+ *   1 "reference work": the same pipeline, but every query the reference performs is performed as a
+ *               full closest-hit query, and exact counters are kept (gpuart_hip_counters);
+ *   2 megakernel: one thread runs a whole path (the first correct version; kept for A/B and cross-checks). */
+int gpuart_hip_set_mode(gpuart_hip_ctx *ctx, int mode);
 int gpuart_hip_counters(gpuart_hip_ctx *ctx, gpuart_counters *out, int reset);
 
-/* HIP-event timing of the render kernels launched since the last reset (events are recorded on
- * the context's stream around each direct / pt_pass kernel). */
-int gpuart_hip_kernel_time(gpuart_hip_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
+/* HIP-event timing on the context's stream. Level 0: none; 1 (default): one event pair around every
+ * render call (class 0); 2: additionally one pair around every BVH-query kernel (class 1).
+ * gpuart_hip_kernel_time returns the sum and the count of class `cls` since its last reset. */
+int gpuart_hip_set_timing(gpuart_hip_ctx *ctx, int level);
+int gpuart_hip_kernel_time(gpuart_hip_ctx *ctx, int cls, double *total_ms, uint64_t *launches, int reset);
 
 /* Scene statistics after upload: node count, primitive count, tree depth, device bytes. */
 int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims, uint32_t *max_depth,

@@ -172,10 +172,10 @@ def deep_chain_scene(n=40):
     return [(S.SPHERE, [float(2.0 ** k), 0.0, 0.0, float(2.0 ** (k - 2))]) for k in range(n)]
 
 
-def test_deep_tree_uses_stackless_walk(be, O):
+def test_deep_tree_spills_the_ring_stack(be, O):
     prims = deep_chain_scene()
     tree, depth = O.build_bvh(prims)
-    assert depth > 32
+    assert depth > 16
     be.upload_bvh(tree)
     assert be.scene_info()["max_depth"] == depth
     rng = np.random.RandomState(5)
@@ -186,7 +186,7 @@ def test_deep_tree_uses_stackless_walk(be, O):
     e0, e1 = O.traverse(tree, rs, rd, S.USER_SPHERE)
     o0, o1 = be.test_traverse(rs, rd, S.USER_SPHERE)
     assert (e1[:, 3] >= 0).mean() > 0.3
-    assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "stackless closest hit")
+    assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "closest hit through the spill path")
 
 
 # ---- frames -----------------------------------------------------------------------------------------
@@ -229,6 +229,79 @@ def test_frames_vs_reference_goldens(B, be, O, name):
         check_frame(be.read(1), g["pt_3paths"], "PT 3 paths/pass")
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", ["frames_box_seg5", "frames_scene_pc_seg5", "frames_scene_d_seg8", "frames_box_usph_fuzzy",
+                                  "frames_box_usph_em"])
+def test_other_execution_modes_give_identical_frames(B, be, O, name, mode):
+    """reference-work pipeline (1) and megakernel (2) against the same goldens as the default pipeline."""
+    g = golden(name)
+    W, H = int(g["W"]), int(g["H"])
+    tree, _ = O.build_bvh(scene(str(g["scene"])))
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(g["cam"])
+    mk = frame_golden_params(O, g)
+    be.set_mode(mode)
+    try:
+        if "direct" in g:
+            be.render_direct(to_params(B, mk()))
+            check_frame(be.read(0), g["direct"], "direct")
+        npass = int(g["npasses"]) if "npasses" in g else 2
+        be.pt_reset()
+        for k in range(npass):
+            be.pt_pass(to_params(B, mk()), g["seeds"][k], 1)
+        check_frame(be.read(1), g["pt_acc"], "PT accumulated")
+        if "pt_3paths" in g:
+            be.pt_reset()
+            be.pt_pass(to_params(B, mk()), g["seeds"][0], 3)
+            check_frame(be.read(1), g["pt_3paths"], "PT 3 paths/pass")
+    finally:
+        be.set_mode(0)
+
+
+def test_deep_tree_frames(B, be, O):
+    """A 39-level tree (deeper than the LDS ring stack): frames through the spill path == oracle."""
+    prims = deep_chain_scene() + [(S.DISC, [0, 0, -0.3, 0, 0, 1, 40])]
+    tree, depth = O.build_bvh(prims)
+    assert depth > 16
+    W, H = 96, 64
+    cam = dict(pos=(-6.0, -9.0, 4.0), up=(0.0, 0.0, 1.0), fov_y=60.0, screen_dist=0.2)
+    cam["dir"] = (8.0, 9.0, -4.0)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    seeds = O.randseeds(2)
+    acc = np.zeros((H, W, 4), np.float32)
+    be.pt_reset()
+    for k in range(2):
+        be.pt_pass(to_params(B, P), seeds[k], 1)
+        O.pt_pass(tree, c, W, H, P, seeds[k], 1, acc)
+    assert (acc[..., :3].sum(-1) > 0).mean() > 0.5
+    assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "deep tree PT")
+    be.render_direct(to_params(B, P))
+    exp, _ = O.render_direct(tree, c, W, H, P)
+    assert_bits(be.read(0)[..., :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "deep tree direct")
+
+
+def test_segment_and_weight_limits(B, be, O):
+    """maxSegments / minWeight edge values: 0 segments, weight >= 1, weight 0 with a long segment budget."""
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    W, H = 64, 40
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    tree, _ = O.build_bvh(scene("box"))
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    for ms, mw in [(0, 0.01), (5, 1.0), (5, 1.5), (12, 0.0), (3, 0.2), (2, 0.01)]:
+        P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], ms, mw)
+        acc = np.zeros((H, W, 4), np.float32)
+        O.pt_pass(tree, c, W, H, P, [0.3, 0.6, 0.9, 0.1], 2, acc)
+        for mode in (0, 2):
+            be.set_mode(mode)
+            be.pt_reset()
+            be.pt_pass(to_params(B, P), [0.3, 0.6, 0.9, 0.1], 2)
+            assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "maxSegments=%d minWeight=%g mode %d" % (ms, mw, mode))
+        be.set_mode(0)
+
+
 def test_renderer_api_box_scene(B):
     """The C++ gpuart::Renderer driven like the reference app drives it (src/main.cpp:609-623,549-599)."""
     g = golden("frames_box_seg5")
@@ -260,7 +333,7 @@ def test_reference_work_mode_counters_match_oracle(B, be, O):
     be.upload_bvh(tree)
     be.set_camera(g["cam"])
     mk = frame_golden_params(O, g)
-    be.set_mode(True)
+    be.set_mode(1)
     try:
         be.counters(reset=True)
         be.render_direct(to_params(B, mk()))
@@ -276,7 +349,7 @@ def test_reference_work_mode_counters_match_oracle(B, be, O):
         st = O.pt_pass(tree, g["cam"], W, H, mk(), g["seeds"][0], 1, acc, nthreads=4)
         assert (c.rays, c.nodes, list(c.prim_tests), c.segments) == (st.rays, st.nodes, list(st.prim_tests), st.segments)
     finally:
-        be.set_mode(False)
+        be.set_mode(0)
 
 
 # ---- edge cases ---------------------------------------------------------------------------------------
