@@ -1,16 +1,20 @@
 // device_scene.h — device-side scene layout, primitive intersectors and BVH traversal.
 //
 // Device layout (built by the uploader from the reference's canonical quad array):
-//   nodes : float4[2*N], node n (pre-order ordinal; the lower child of n is n+1):
-//             [2n]   = { bbmin.xyz, bits(link) }   link = hi-child ordinal (interior) |
-//                                                         first primitive index (leaf)
-//             [2n+1] = { bbmax.xyz, bits(meta) }   meta = bit31 leaf | primitive count
+//   recs  : float4[4*R], one 64-byte record per INTERIOR node (pre-order; the record of an interior
+//           lower child directly follows its parent's), holding the boxes of BOTH children so that one
+//           fetch of one 64-byte line serves two box tests:
+//             [4r]   = { lo.bbmin.xyz, bits(lo ref) }     ref = record index of an interior child, or
+//             [4r+1] = { lo.bbmax.xyz, bits(hi ref) }           bit31 | first primitive index of a leaf child
+//             [4r+2] = { hi.bbmin.xyz, 0 }
+//             [4r+3] = { hi.bbmax.xyz, 0 }
+//           The root's own box and ref travel in the Scene struct.
 //   prims : float4[3*P], fixed 48-byte records, primitive p at [3p..3p+2]:
 //             sphere   { c.xyz, T }{ r, 0, 0, 0 }{ 0 }
 //             disc     { c.xyz, T }{ n.xyz, r }{ 0 }
 //             triangle { v0.xyz, T }{ e1.xyz, 0 }{ e2.xyz, 0 }     e1 = v1-v0, e2 = v2-v0 (fp32)
 //             cone     { c1.xyz, T }{ axis.xyz, len }{ r1, widthCoeff, cosB, dotAxC1 }
-//           T = bits(type)
+//           T = bits(type | count << 2): the FIRST primitive of a leaf carries the leaf's primitive count
 #pragma once
 #include "device_math.h"
 
@@ -22,9 +26,13 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #define GD_USER_SPHERE 0xfffffffeu
 #define GD_META_LEAF 0x80000000u
 
+#define GD_REF_LEAF 0x80000000u
+
 struct Scene {
-    const float4 *__restrict__ nodes;
+    const float4 *__restrict__ recs;
     const float4 *__restrict__ prims;
+    float root_min[3], root_max[3];
+    uint32_t root_ref;    ///< record index, or GD_REF_LEAF | first primitive
     uint32_t num_nodes;
     uint32_t max_depth;
 };
@@ -143,7 +151,7 @@ GD_FN void cone_hit(const Ray &r, F3 c1, float r1, F3 ax, float axLen, float wid
 /// One primitive record against a ray (reference CheckBVHPrimitiveIntersection,
 /// shaders/bvh_intersection.glsl:125-223, including its `pos < VISIBILITY_OFFSET -> -1` cut).
 GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F3 &p, F3 &n, int &ptype) {
-    ptype = (int)__float_as_uint(q0.w);
+    ptype = (int)(__float_as_uint(q0.w) & 3u);
     if (ptype == P_TRIANGLE) triangle_hit(r, xyz(q0), xyz(q1), xyz(q2), pos, p, n);
     else if (ptype == P_SPHERE) sphere_hit(r, xyz(q0), q1.x, pos, p, n);
     else if (ptype == P_DISC) disc_hit(r, xyz(q0), q1.w, xyz(q1), pos, p, n);
@@ -151,51 +159,49 @@ GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F
     if (pos < GD_VISIBILITY_OFFSET) pos = -1;
 }
 
-/// Ray/AABB entry test (reference IntersectsAABB, shaders/bvh_intersection.glsl:229-354).
-/// Returns false on a miss; pos = -1 when the origin is inside (inclusive), else the smallest
-/// non-negative plane parameter whose hit point lies within the face (inclusive bounds).
+/// Ray/AABB entry test (reference IntersectsAABB, shaders/bvh_intersection.glsl:229-354), written
+/// without branches: the same six plane parameters, the same face-bounds checks (inclusive), the same
+/// running minimum, combined with selects. Returns false on a miss; pos = -1 when the origin is inside
+/// (inclusive), else the smallest non-negative plane parameter whose hit point lies within the face.
+GD_FN bool within(float v, float lo, float hi) { return v >= lo && v <= hi; }
+
 GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos) {
-    if (r.o.x >= bmin.x && r.o.y >= bmin.y && r.o.z >= bmin.z && r.o.x <= bmax.x && r.o.y <= bmax.y && r.o.z <= bmax.z) {
-        pos = -1;
-        return true;
-    }
+    const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
+    float best = 1.0e+19f;
     bool hit = false;
-    pos = 1.0e+19f;
-#define GD_FACE(K, A0, B0, A1, B1, LOA, HIA, LOB, HIB)                         \
-    {                                                                          \
-        float k = (K);                                                         \
-        if (k >= 0) {                                                          \
-            float a = (A0) + k * (A1), b = (B0) + k * (B1);                    \
-            if (a >= (LOA) && a <= (HIA) && b >= (LOB) && b <= (HIB)) {        \
-                hit = true;                                                    \
-                if (k < pos) pos = k;                                          \
-            }                                                                  \
-        }                                                                      \
+#define GD_FACE(NZ, K, A0, B0, A1, B1, LOA, HIA, LOB, HIB)                                        \
+    {                                                                                             \
+        const float k = (K);                                                                      \
+        const float a = (A0) + k * (A1), b = (B0) + k * (B1);                                     \
+        const bool ok = (NZ) & (k >= 0) & within(a, LOA, HIA) & within(b, LOB, HIB);              \
+        hit |= ok;                                                                                \
+        best = (ok & (k < best)) ? k : best;                                                      \
     }
-    if (r.d.x != 0) {
-        GD_FACE((bmin.x - r.o.x) * rdiv.x, r.o.y, r.o.z, r.d.y, r.d.z, bmin.y, bmax.y, bmin.z, bmax.z)
-        GD_FACE((bmax.x - r.o.x) * rdiv.x, r.o.y, r.o.z, r.d.y, r.d.z, bmin.y, bmax.y, bmin.z, bmax.z)
-    }
-    if (r.d.y != 0) {
-        GD_FACE((bmin.y - r.o.y) * rdiv.y, r.o.x, r.o.z, r.d.x, r.d.z, bmin.x, bmax.x, bmin.z, bmax.z)
-        GD_FACE((bmax.y - r.o.y) * rdiv.y, r.o.x, r.o.z, r.d.x, r.d.z, bmin.x, bmax.x, bmin.z, bmax.z)
-    }
-    if (r.d.z != 0) {
-        GD_FACE((bmin.z - r.o.z) * rdiv.z, r.o.x, r.o.y, r.d.x, r.d.y, bmin.x, bmax.x, bmin.y, bmax.y)
-        GD_FACE((bmax.z - r.o.z) * rdiv.z, r.o.x, r.o.y, r.d.x, r.d.y, bmin.x, bmax.x, bmin.y, bmax.y)
-    }
+    const bool nx = r.d.x != 0, ny = r.d.y != 0, nz = r.d.z != 0;
+    GD_FACE(nx, (bmin.x - r.o.x) * rdiv.x, r.o.y, r.o.z, r.d.y, r.d.z, bmin.y, bmax.y, bmin.z, bmax.z)
+    GD_FACE(nx, (bmax.x - r.o.x) * rdiv.x, r.o.y, r.o.z, r.d.y, r.d.z, bmin.y, bmax.y, bmin.z, bmax.z)
+    GD_FACE(ny, (bmin.y - r.o.y) * rdiv.y, r.o.x, r.o.z, r.d.x, r.d.z, bmin.x, bmax.x, bmin.z, bmax.z)
+    GD_FACE(ny, (bmax.y - r.o.y) * rdiv.y, r.o.x, r.o.z, r.d.x, r.d.z, bmin.x, bmax.x, bmin.z, bmax.z)
+    GD_FACE(nz, (bmin.z - r.o.z) * rdiv.z, r.o.x, r.o.y, r.d.x, r.d.y, bmin.x, bmax.x, bmin.y, bmax.y)
+    GD_FACE(nz, (bmax.z - r.o.z) * rdiv.z, r.o.x, r.o.y, r.d.x, r.d.y, bmin.x, bmax.x, bmin.y, bmax.y)
 #undef GD_FACE
-    return hit;
+    pos = inside ? -1.0f : best;
+    return inside | hit;
 }
 
-/// Tests the `count` primitives of a leaf; keeps the strictly closer hit (first one wins ties,
-/// reference shaders/bvh_intersection.glsl:405-423). Returns true if ANY_HIT and something was hit.
+/// Tests the primitives of the leaf starting at primitive `first` (its count sits in the first record's
+/// type word); keeps the strictly closer hit (the first one wins ties, reference
+/// shaders/bvh_intersection.glsl:405-423). Returns true if ANY_HIT and something was hit.
 template <bool ANY_HIT, bool COUNT>
-GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, uint32_t count, float &closest, uint32_t &hit_prim,
-                     WorkCounters *wc) {
+GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+    uint32_t count = 1;
     for (uint32_t i = 0; i < count; i++) {
         uint32_t pi = first + i;
-        float4 q0 = sc.prims[3 * pi], q1 = sc.prims[3 * pi + 1], q2 = sc.prims[3 * pi + 2];
+        float4 q0 = sc.prims[3 * (size_t)pi], q1 = sc.prims[3 * (size_t)pi + 1], q2 = sc.prims[3 * (size_t)pi + 2];
+        if (i == 0) {
+            count = __float_as_uint(q0.w) >> 2;
+            if (count == 0) break;  // empty leaf (empty scene)
+        }
         float pos; F3 p, n; int ptype;
         prim_hit(r, q0, q1, q2, pos, p, n, ptype);
         if (COUNT) wc->prims[ptype & 3]++;
@@ -209,104 +215,146 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, uint32_t cou
 }
 
 // ---- traversal stack: short per-lane ring in LDS + spill to global memory -------------------------
-// Entry = (upper-child ordinal, parent's box-entry parameter). Entries [base, sp) live in the LDS ring
-// (slot = index % RING, one column per lane -> conflict-free 8-byte accesses); entries [0, base) live in
-// a per-lane global spill column. The oldest entries (closest to the root, popped last) are the ones
-// spilled, so spills are rare; any tree depth up to the reference's 1024 levels works without a
-// separate code path.
+// Entry = (upper child's ref, parent's box-entry parameter, the child's own box-entry parameter).
+// Entries [base, sp) live in the LDS ring (slot = index % RING, one column per
+// lane -> conflict-free accesses); entries [0, base) live in a per-lane global spill column. The oldest
+// entries (closest to the root, popped last) are the ones spilled, so spills are rare; any tree depth
+// up to the reference's 1024 levels works without a separate code path.
+#ifndef GD_RING
 #define GD_RING 16
+#endif
+
+struct StackEntry {
+    uint32_t ref;   ///< upper child: record index, or GD_REF_LEAF | first primitive
+    float pe, he;   ///< box-entry parameter of the parent / of the child itself (GD_ENTRY_MISS: box not hit)
+};
 
 struct TravStack {
-    uint2 *ring;             ///< LDS, [GD_RING][BLOCK] ; this lane's column is ring[slot * BLOCK]
-    uint2 *spill;            ///< global, [levels][total_lanes]; this lane's column is spill[level * stride]
+    uint2 *ring_a;           ///< LDS, [GD_RING][BLOCK]: (ref, pe)
+    float *ring_b;           ///< LDS, [GD_RING][BLOCK]: he
+    uint4 *spill;            ///< global, [levels][total_lanes]; this lane's column is spill[level * spill_stride]
     uint32_t ring_stride;    ///< BLOCK
     uint32_t spill_stride;   ///< total lanes of the launch
     uint32_t sp, base;
     GD_FN void reset() { sp = 0; base = 0; }
-    GD_FN void push(uint2 e) {
+    GD_FN void push(StackEntry e) {
         if (sp - base == GD_RING) {
-            spill[(size_t)base * spill_stride] = ring[(base & (GD_RING - 1)) * ring_stride];
+            uint32_t o = (base & (GD_RING - 1)) * ring_stride;
+            uint2 a = ring_a[o];
+            spill[(size_t)base * spill_stride] = make_uint4(a.x, a.y, __float_as_uint(ring_b[o]), 0);
             base++;
         }
-        ring[(sp & (GD_RING - 1)) * ring_stride] = e;
+        uint32_t o = (sp & (GD_RING - 1)) * ring_stride;
+        ring_a[o] = make_uint2(e.ref, __float_as_uint(e.pe));
+        ring_b[o] = e.he;
         sp++;
     }
-    GD_FN uint2 pop() {  // precondition: sp > 0
+    GD_FN StackEntry pop() {  // precondition: sp > 0
         if (sp == base) {
             base--;
-            ring[(base & (GD_RING - 1)) * ring_stride] = spill[(size_t)base * spill_stride];
+            uint4 v = spill[(size_t)base * spill_stride];
+            uint32_t o = (base & (GD_RING - 1)) * ring_stride;
+            ring_a[o] = make_uint2(v.x, v.y);
+            ring_b[o] = __uint_as_float(v.z);
         }
         sp--;
-        return ring[(sp & (GD_RING - 1)) * ring_stride];
+        uint32_t o = (sp & (GD_RING - 1)) * ring_stride;
+        uint2 a = ring_a[o];
+        StackEntry e;
+        e.ref = a.x; e.pe = __uint_as_float(a.y); e.he = ring_b[o];
+        return e;
     }
 };
 
 /// Traversal state of one ray. The walk visits exactly the nodes, in exactly the order, of the
 /// reference's stackless parent-pointer walk (shaders/bvh_intersection.glsl:360-457): lower child
-/// first, prune on `entry > closest`; where the reference re-tests a parent's box when it returns
-/// from the lower child, the parent's entry parameter kept on the stack is compared with the current
-/// closest hit instead (same value: the test is a pure function of node and ray).
+/// first, prune on `entry > closest`. Where the reference re-tests a parent's box when it returns from
+/// the lower child, the parent's entry parameter kept on the stack is compared with the current closest
+/// hit (same value: the test is a pure function of node and ray). The upper child's box is tested when
+/// its parent's record is fetched (both boxes share one 64-byte record) and the result waits on the
+/// stack; whether it is *used* is decided exactly where the reference decides it, at pop time.
 enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2 };
+
+#define GD_ENTRY_MISS 3.0e+38f  // stack marker: the upper child's box is not hit at all
 
 struct Trav {
     float closest;
     uint32_t hit_prim;
-    uint32_t node;       ///< DESCEND: node to test; LEAF: first primitive index
-    uint32_t leaf_count; ///< LEAF: number of primitives
+    uint32_t node;       ///< DESCEND: record to fetch; LEAF: first primitive index
+    float entry;         ///< DESCEND: box-entry parameter of the node whose record is `node`
     int state;
 };
 
-GD_FN void trav_init(Trav &t, TravStack &st) {
-    t.closest = 1e+19f;
-    t.hit_prim = GD_NO_PRIM;
-    t.node = 0;
-    t.leaf_count = 0;
-    t.state = TRAV_DESCEND;
-    st.reset();
+/// Enters a child whose box test passed: a leaf waits for its primitive tests, an interior child for its record.
+GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
+    if (ref & GD_REF_LEAF) {
+        t.node = ref & ~GD_REF_LEAF;
+        t.state = TRAV_LEAF;
+    } else {
+        t.node = ref;
+        t.entry = entry;
+        t.state = TRAV_DESCEND;
+    }
 }
 
 /// Returns to the nearest pending upper child that is still worth visiting (or finishes).
-GD_FN void trav_pop(Trav &t, TravStack &st) {
+template <bool COUNT>
+GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc) {
     for (;;) {
         if (st.sp == 0) { t.state = TRAV_DONE; return; }
-        uint2 e = st.pop();
-        if (__uint_as_float(e.y) > t.closest) continue;  // the reference's parent re-test
-        t.node = e.x;
-        t.state = TRAV_DESCEND;
+        StackEntry e = st.pop();
+        if (e.pe > t.closest) continue;   // the reference's parent re-test fails: skip the upper child
+        if (COUNT) wc->nodes++;           // the reference tests the upper child's box now
+        if (e.he > t.closest) continue;   // box missed (GD_ENTRY_MISS), or entered beyond the closest hit
+        trav_enter(t, e.ref, e.he);
         return;
     }
 }
 
-/// One node visit: box test, then descend / mark leaf / pop. Precondition: state == DESCEND.
+GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool count) {
+    t.closest = 1e+19f;
+    t.hit_prim = GD_NO_PRIM;
+    t.node = 0;
+    t.entry = 0;
+    st.reset();
+    if (count) { wc->rays++; wc->nodes++; }
+    float entry;
+    bool hit = aabb_entry(r, rdiv, f3(sc.root_min[0], sc.root_min[1], sc.root_min[2]),
+                          f3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), entry);
+    if (hit) trav_enter(t, sc.root_ref, entry);  // entry > 1e19 cannot happen
+    else t.state = TRAV_DONE;
+}
+
+/// One interior-node visit: fetch its record, test both children's boxes, descend / stack / pop.
+/// Precondition: state == DESCEND.
 template <bool COUNT>
 GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc) {
-    float4 n0 = sc.nodes[2 * t.node], n1 = sc.nodes[2 * t.node + 1];
-    if (COUNT) wc->nodes++;
-    float entry;
-    bool hit = aabb_entry(r, rdiv, xyz(n0), xyz(n1), entry);
-    if (hit && !(entry > t.closest)) {
-        uint32_t meta = __float_as_uint(n1.w), link = __float_as_uint(n0.w);
-        if (meta & GD_META_LEAF) {
-            t.node = link;
-            t.leaf_count = meta & ~GD_META_LEAF;
-            t.state = TRAV_LEAF;
-        } else {
-            st.push(make_uint2(link, __float_as_uint(entry)));
-            t.node = t.node + 1;
-        }
+    const float4 *rec = sc.recs + 4 * (size_t)t.node;
+    float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    float el, eh;
+    bool hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
+    bool hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
+    if (COUNT) wc->nodes++;  // the lower child's box test (the upper one is counted when the reference reaches it)
+    if (COUNT || hh) {
+        StackEntry e;
+        e.ref = __float_as_uint(q1.w); e.pe = t.entry; e.he = hh ? eh : GD_ENTRY_MISS;
+        st.push(e);
+    }
+    if (hl && !(el > t.closest)) {
+        trav_enter(t, __float_as_uint(q0.w), el);
         return;
     }
-    trav_pop(t, st);
+    trav_pop<COUNT>(t, st, wc);
 }
 
 /// Tests the primitives of the pending leaf, then pops. Precondition: state == LEAF.
 template <bool ANY_HIT, bool COUNT>
 GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
-    if (leaf_test<ANY_HIT, COUNT>(sc, r, t.node, t.leaf_count, t.closest, t.hit_prim, wc) && ANY_HIT) {
+    if (leaf_test<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc) && ANY_HIT) {
         t.state = TRAV_DONE;
         return;
     }
-    trav_pop(t, st);
+    trav_pop<COUNT>(t, st, wc);
 }
 
 /// Runs one query to completion (megakernels and test hooks).
@@ -314,8 +362,7 @@ template <bool ANY_HIT, bool COUNT>
 GD_FN void traverse(const Scene &sc, const Ray &r, TravStack &st, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
     F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
     Trav t;
-    trav_init(t, st);
-    if (COUNT) wc->rays++;
+    trav_init(sc, r, rdiv, t, st, wc, COUNT);
     while (t.state != TRAV_DONE) {
         if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, r, rdiv, t, st, wc);
         else trav_step_leaf<ANY_HIT, COUNT>(sc, r, t, st, wc);

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,9 +17,14 @@
 using namespace gd;
 
 #define BLOCK 64          // one wavefront per workgroup
-#define FETCH_CHUNK 64    // rays a wave takes from a queue per atomic
-#define REFILL_LANES 16   // a traversal wave goes back for new rays once this many lanes are idle
-#define LEAF_LANES 12     // leaf (primitive) code runs once this many lanes wait at a leaf
+
+/// Scheduling knobs of the persistent BVH-query kernel (defaults chosen by tools/sweep.py on MI355X;
+/// overridable through GPUART_HIP_* environment variables for tuning runs; results never depend on them).
+struct TraceTuning {
+    uint32_t chunk;         ///< rays a wave takes from a queue per fetch
+    uint32_t refill_lanes;  ///< a wave goes back for new rays once this many lanes are idle
+    uint32_t leaf_lanes;    ///< primitive tests are issued once this many lanes wait at a leaf
+};
 
 // =================================================================================================
 // Kernels
@@ -62,9 +68,10 @@ GD_FN bool slot_pixel(const Frame &f, uint32_t slot, uint32_t &lx, uint32_t &ly)
     return lx < f.tw && ly < f.th;
 }
 
-GD_FN TravStack make_stack(uint2 *ring, uint2 *spill, uint32_t total_lanes) {
+GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes) {
     TravStack st;
-    st.ring = ring + lane_id();
+    st.ring_a = ring_a + lane_id();
+    st.ring_b = ring_b + lane_id();
     st.ring_stride = BLOCK;
     st.spill = spill + (size_t)blockIdx.x * BLOCK + lane_id();
     st.spill_stride = total_lanes;
@@ -133,33 +140,39 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, float4 
 // wave-wide phases (leaf code waits until LEAF_LANES lanes need it).
 template <bool SHADOW, bool ANY, bool COUNT>
 __global__ void __launch_bounds__(BLOCK) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
-                                                 int npaths, float4 *accum, uint2 *spill, unsigned long long *gcounters) {
-    __shared__ uint2 ring[GD_RING * BLOCK];
-    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+                                                 int npaths, float4 *accum, uint4 *spill, unsigned long long *gcounters,
+                                                 TraceTuning tune) {
+    __shared__ uint2 ring_a[GD_RING * BLOCK];
+    __shared__ float ring_b[GD_RING * BLOCK];
+    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
     const uint32_t *queue = SHADOW ? b.shadow_queue : b.queue[seg & 1];
     const uint32_t n = b.counters[4 * seg + (SHADOW ? 2 : 0)];
     uint32_t *cursor = &b.counters[4 * seg + (SHADOW ? 3 : 1)];
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     WorkCounters wc = {0, 0, {0, 0, 0, 0}};
 
-    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
-    bool exhausted = false;                  // wave-uniform
+    // The first chunk of every wave is static (chunk index = workgroup index); later chunks come from the
+    // shared cursor, which therefore starts behind the static ones. No atomic at all for small queues.
+    const uint32_t static_end = gridDim.x * tune.chunk;
+    uint32_t chunk_next = min(blockIdx.x * tune.chunk, n), chunk_end = min((blockIdx.x + 1) * tune.chunk, n);  // wave-uniform
+    bool exhausted = false;                                                                                   // wave-uniform
     uint32_t slot = SLOT_INVALID;
     Ray r; r.o = f3(0, 0, 0); r.d = f3(1, 0, 0);
     F3 rdiv = f3(1, 1, 1);
-    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.leaf_count = 0;
+    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
 
     for (;;) {
         // ---- refill idle lanes from the queue
         unsigned long long idle = __ballot(slot == SLOT_INVALID);
         while (idle && !exhausted) {
             if (chunk_next == chunk_end) {
+                if (static_end >= n) { exhausted = true; break; }
                 uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(cursor, (uint32_t)FETCH_CHUNK);
-                base = __shfl(base, 0, 64);
+                if (lane_id() == 0) base = atomicAdd(cursor, tune.chunk);
+                base = __shfl(base, 0, 64) + static_end;
                 if (base >= n) { exhausted = true; break; }
                 chunk_next = base;
-                chunk_end = min(base + (uint32_t)FETCH_CHUNK, n);
+                chunk_end = min(base + tune.chunk, n);
             }
             uint32_t want = (uint32_t)__popcll(idle), take = min(want, chunk_end - chunk_next);
             uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1));
@@ -170,8 +183,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace(Scene sc, Frame f, gpuart_param
                     r.o = xyz(b.ray_o[s]);
                     r.d = SHADOW ? sun : xyz(b.ray_d[s]);
                     rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
-                    trav_init(t, st);
-                    if (COUNT) wc.rays++;
+                    trav_init(sc, r, rdiv, t, st, &wc, COUNT);
                 }
             }
             chunk_next += take;
@@ -187,14 +199,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace(Scene sc, Frame f, gpuart_param
             if (slot != SLOT_INVALID && t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, r, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && t.state == TRAV_LEAF);
             unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
-            if (at_leaf && ((uint32_t)__popcll(at_leaf) >= LEAF_LANES || !descending)) {
+            if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
                 if (slot != SLOT_INVALID && t.state == TRAV_LEAF) trav_step_leaf<ANY, COUNT>(sc, r, t, st, COUNT ? &wc : nullptr);
                 descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
                 at_leaf = __ballot(slot != SLOT_INVALID && t.state == TRAV_LEAF);
             }
             unsigned long long busy = descending | at_leaf;
             if (!busy) break;
-            if (!exhausted && 64u - (uint32_t)__popcll(busy) >= REFILL_LANES) break;
+            if (!exhausted && 64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
         }
         // ---- retire finished rays
         if (slot != SLOT_INVALID && t.state == TRAV_DONE) {
@@ -264,9 +276,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
 // ---- megakernels: one thread per pixel, persistent grid over 8x8 tiles -------------------------------------
 template <bool REFWORK>
 __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_params P, uint32_t n_slots, float4 *__restrict__ out,
-                                                  uint2 *spill, unsigned long long *counters) {
-    __shared__ uint2 ring[GD_RING * BLOCK];
-    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+                                                  uint4 *spill, unsigned long long *counters) {
+    __shared__ uint2 ring_a[GD_RING * BLOCK];
+    __shared__ float ring_b[GD_RING * BLOCK];
+    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
     WorkCounters wc = {0, 0, {0, 0, 0, 0}};
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;
@@ -281,9 +294,10 @@ __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_para
 
 template <bool REFWORK>
 __global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_params P, float4 seed, int npaths, uint32_t n_slots,
-                                                   float4 *__restrict__ accum, uint2 *spill, unsigned long long *counters) {
-    __shared__ uint2 ring[GD_RING * BLOCK];
-    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+                                                   float4 *__restrict__ accum, uint4 *spill, unsigned long long *counters) {
+    __shared__ uint2 ring_a[GD_RING * BLOCK];
+    __shared__ float ring_b[GD_RING * BLOCK];
+    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
     WorkCounters wc = {0, 0, {0, 0, 0, 0}};
     uint32_t segments = 0;
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
@@ -360,9 +374,10 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
 }
 template <bool ANY>
 __global__ void __launch_bounds__(BLOCK) k_test_traverse(Scene sc, const float4 *rs, const float4 *rd, Float4Arg us, int n,
-                                                         float4 *o0, float4 *o1, uint2 *spill) {
-    __shared__ uint2 ring[GD_RING * BLOCK];
-    TravStack st = make_stack(ring, spill, gridDim.x * BLOCK);
+                                                         float4 *o0, float4 *o1, uint4 *spill) {
+    __shared__ uint2 ring_a[GD_RING * BLOCK];
+    __shared__ float ring_b[GD_RING * BLOCK];
+    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
         float closest; uint32_t prim;
@@ -443,14 +458,17 @@ struct gpuart_hip_ctx {
     Frame frame{};
     bool have_camera = false, have_scene = false;
     float4 *d_nodes = nullptr, *d_prims = nullptr;
-    uint2 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow
+    uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
+    TraceTuning tune{64, 16, 12};
     PathBuffers pb{};              ///< wavefront path state (tile-sized)
     void *d_pathmem = nullptr;
     uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    uint32_t root_ref = 0;
     uint32_t max_depth = 0;
     float4 *d_direct = nullptr, *d_accum = nullptr;
     size_t tile_pixels = 0;
@@ -512,7 +530,7 @@ int ensure_spill(gpuart_hip_ctx *c) {
     const uint32_t levels = c->max_depth > GD_RING ? c->max_depth - GD_RING : 0;
     if (c->d_spill && c->spill_levels >= levels) return 0;
     if (c->d_spill) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_spill); c->d_spill = nullptr; }
-    HIP_TRY(hipMalloc(&c->d_spill, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&c->d_spill, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4)));
     c->spill_levels = levels;
     return 0;
 }
@@ -528,7 +546,9 @@ void update_uv(gpuart_hip_ctx *c) {
 
 Scene scene_of(const gpuart_hip_ctx *c) {
     Scene s;
-    s.nodes = c->d_nodes;
+    s.recs = c->d_nodes;
+    memcpy(s.root_min, c->root_min, 12); memcpy(s.root_max, c->root_max, 12);
+    s.root_ref = c->root_ref;
     s.prims = c->d_prims;
     s.num_nodes = (uint32_t)c->n_nodes;
     s.max_depth = c->max_depth;
@@ -570,7 +590,8 @@ int end_timed(gpuart_hip_ctx *c, TimedLaunch &t) {
 struct Converter {
     const float *q;
     size_t nq;
-    std::vector<float4> nodes, prims;
+    std::vector<float4> recs, prims;
+    size_t num_nodes = 0;
     uint32_t max_depth = 0;
     std::string err;
 
@@ -601,19 +622,26 @@ struct Converter {
         return false;
     }
 
-    bool node(size_t addr, uint32_t parentOrd, bool isLower, uint32_t depth) {
+    /// Result of converting one canonical node: its box and the ref its parent stores for it.
+    struct Child {
+        float bmin[3], bmax[3];
+        uint32_t ref;
+    };
+
+    /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
+    /// interior lower child's record directly follows its parent's); leaves append their primitives.
+    bool node(size_t addr, uint32_t depth, Child &out) {
         if (addr + 3 > nq) { err = "node address out of range"; return false; }
         if (depth > 1024) { err = "tree deeper than 1024 levels"; return false; }
         if (depth > max_depth) max_depth = depth;
-        uint32_t ord = (uint32_t)(nodes.size() / 2);
+        num_nodes++;
         const float *b = q + 4 * addr;
+        for (int k = 0; k < 3; k++) { out.bmin[k] = b[k]; out.bmax[k] = b[4 + k]; }
         uint32_t flags = bits(b[8]);
-        nodes.push_back(make_float4(b[0], b[1], b[2], 0));
-        nodes.push_back(make_float4(b[4], b[5], b[6], 0));
-        (void)parentOrd; (void)isLower;
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
             uint32_t first = (uint32_t)(prims.size() / 3);
+            if (first >= 0x80000000u) { err = "too many primitives"; return false; }
             size_t a = addr + 3;
             static const int LEN[4] = {1, 2, 3, 4};
             for (uint32_t i = 0; i < n; i++) {
@@ -623,21 +651,31 @@ struct Converter {
                 if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
                 float4 rec[3];
                 pack_prim(type, q + 4 * (a + 1), rec);
+                if (i == 0) rec[0].w = fbits(type | (n << 2));  // the first primitive carries the leaf's count
                 prims.push_back(rec[0]); prims.push_back(rec[1]); prims.push_back(rec[2]);
                 a += 1 + LEN[type];
             }
-            nodes[2 * ord].w = fbits(first);
-            nodes[2 * ord + 1].w = fbits(0x80000000u | n);
+            if (n == 0) {  // empty leaf (empty scene): one dummy record with count 0
+                prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
+            }
+            out.ref = GD_REF_LEAF | first;
             return true;
         }
         uint32_t lo = bits(b[9]), hi = bits(b[10]);
         if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
         if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
-        if (!node(lo, ord, true, depth + 1)) return false;
-        uint32_t hiOrd = (uint32_t)(nodes.size() / 2);
-        nodes[2 * ord].w = fbits(hiOrd);
-        nodes[2 * ord + 1].w = fbits(0);
-        return node(hi, ord, false, depth + 1);
+        const size_t r = recs.size() / 4;
+        if (r >= 0x80000000u) { err = "too many nodes"; return false; }
+        recs.resize(recs.size() + 4);
+        Child L, H;
+        if (!node(lo, depth + 1, L)) return false;
+        if (!node(hi, depth + 1, H)) return false;
+        recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
+        recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
+        recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], 0);
+        recs[4 * r + 3] = make_float4(H.bmax[0], H.bmax[1], H.bmax[2], 0);
+        out.ref = (uint32_t)r;
+        return true;
     }
 };
 
@@ -706,7 +744,16 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     if (!c) return fail(GPUART_HIP_ERR_DEVICE, "out of host memory");
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-    c->grid_waves = c->num_cus * 16;  // persistent grids: up to 16 one-wave workgroups per CU
+    auto env_u32 = [](const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+        const char *v = getenv(name);
+        if (!v) return dflt;
+        long x = strtol(v, nullptr, 10);
+        return (uint32_t)std::min<long>(hi, std::max<long>(lo, x));
+    };
+    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 16, 1, 32);  // persistent grids of one-wave workgroups
+    c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
+    c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
+    c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 12, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
@@ -752,14 +799,17 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     HIP_TRY(hipSetDevice(c->device));
     Converter cv;
     cv.q = quads; cv.nq = nquads;
-    if (!cv.node(0, 0, false, 0)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
+    Converter::Child root;
+    if (!cv.node(0, 0, root)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
     int r;
-    if ((r = upload_vec(c, c->d_nodes, cv.nodes))) return r;
+    if ((r = upload_vec(c, c->d_nodes, cv.recs))) return r;
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
-    c->n_nodes = cv.nodes.size() / 2;
+    memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
+    c->root_ref = root.ref;
+    c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
     c->max_depth = cv.max_depth;
-    c->scene_bytes = cv.nodes.size() * 16 + cv.prims.size() * 16;
+    c->scene_bytes = cv.recs.size() * 16 + cv.prims.size() * 16;
     if ((r = ensure_spill(c))) return r;
     c->have_scene = true;
     return 0;
@@ -843,15 +893,15 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
             TimedLaunch tt;
             const bool detail = c->timing_level >= 2;
             if (detail && (r = begin_timed(c, tt, 1))) return r;
-            if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
-            else k_trace<false, false, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
+            if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
+            else k_trace<false, false, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
             if (detail && (r = end_timed(c, tt))) return r;
             if (refwork) k_shade<true><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
             else k_shade<false><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
             if (p->sunEnabled == 1) {
                 if (detail && (r = begin_timed(c, tt, 1))) return r;
-                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
-                else k_trace<true, true, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters);
+                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
+                else k_trace<true, true, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
                 if (detail && (r = end_timed(c, tt))) return r;
             }
         }
