@@ -17,6 +17,7 @@
 using namespace gd;
 
 #define BLOCK 64          // one wavefront per workgroup
+#define SHADE_ROUNDS 8    // queue entries per lane a shading wave handles between two queue appends
 
 /// Scheduling knobs of the persistent BVH-query kernel (defaults chosen by tools/sweep.py on MI355X;
 /// overridable through GPUART_HIP_* environment variables for tuning runs; results never depend on them).
@@ -229,13 +230,20 @@ __global__ void __launch_bounds__(BLOCK) k_trace(Scene sc, Frame f, gpuart_param
 template <bool REFWORK>
 __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_params P, float4 seed, PathBuffers b, int seg,
                                                  int j, int npaths, float4 *accum, unsigned long long *gcounters) {
+    // Survivors are appended to the next queues through a per-wave staging list in LDS that is flushed with
+    // ONE atomic per SHADE_ROUNDS*64 processed paths: a single atomic word sustains only ~90 appends/us on
+    // MI355X, and one append per wave per 64 paths made this kernel atomic-bound.
+    __shared__ uint32_t stage_next[SHADE_ROUNDS * BLOCK], stage_shadow[SHADE_ROUNDS * BLOCK];
     const uint32_t n = b.counters[4 * seg];
     const uint32_t *queue = b.queue[seg & 1];
     uint32_t *next_queue = b.queue[(seg + 1) & 1];
     uint32_t segments = 0;
-    const uint32_t rounds = (n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
-    for (uint32_t k = 0; k < rounds; k++) {
-        uint32_t e = (k * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+    const uint32_t span = SHADE_ROUNDS * BLOCK;                 // consecutive queue entries one wave handles at a time
+    const uint32_t spans = (n + span - 1) / span;
+    for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
+      uint32_t n_next = 0, n_shadow = 0;                        // wave-uniform fill of the staging lists
+      for (uint32_t k = 0; k < SHADE_ROUNDS; k++) {
+        uint32_t e = sp * span + k * BLOCK + threadIdx.x;
         uint32_t slot = e < n ? queue[e] : SLOT_INVALID;
         bool go_on = false, shadow = false;
         if (slot != SLOT_INVALID) {
@@ -264,8 +272,25 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
                 if (!go_on && !shadow) path_commit(f, b, accum, slot, j, npaths, pathColor);  // i >= 1: no special case
             }
         }
-        queue_push(next_queue, &b.counters[4 * (seg + 1)], go_on, slot);
-        queue_push(b.shadow_queue, &b.counters[4 * seg + 2], shadow, slot);
+        unsigned long long m1 = __ballot(go_on), m2 = __ballot(shadow);
+        unsigned long long below = (1ull << lane_id()) - 1;
+        if (go_on) stage_next[n_next + (uint32_t)__popcll(m1 & below)] = slot;
+        if (shadow) stage_shadow[n_shadow + (uint32_t)__popcll(m2 & below)] = slot;
+        n_next += (uint32_t)__popcll(m1);
+        n_shadow += (uint32_t)__popcll(m2);
+      }
+      // flush: one atomic per list, then a coalesced copy
+      __syncthreads();
+      uint32_t base1 = 0, base2 = 0;
+      if (lane_id() == 0) {
+          if (n_next) base1 = atomicAdd(&b.counters[4 * (seg + 1)], n_next);
+          if (n_shadow) base2 = atomicAdd(&b.counters[4 * seg + 2], n_shadow);
+      }
+      base1 = __shfl(base1, 0, 64);
+      base2 = __shfl(base2, 0, 64);
+      for (uint32_t i = threadIdx.x; i < n_next; i += BLOCK) next_queue[base1 + i] = stage_next[i];
+      for (uint32_t i = threadIdx.x; i < n_shadow; i += BLOCK) b.shadow_queue[base2 + i] = stage_shadow[i];
+      __syncthreads();
     }
     if (REFWORK) {
         WorkCounters z = {0, 0, {0, 0, 0, 0}};
@@ -462,7 +487,7 @@ struct gpuart_hip_ctx {
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
-    TraceTuning tune{64, 16, 12};
+    TraceTuning tune{64, 16, 1};
     PathBuffers pb{};              ///< wavefront path state (tile-sized)
     void *d_pathmem = nullptr;
     uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
@@ -750,10 +775,10 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
         long x = strtol(v, nullptr, 10);
         return (uint32_t)std::min<long>(hi, std::max<long>(lo, x));
     };
-    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 16, 1, 32);  // persistent grids of one-wave workgroups
+    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 12, 1, 32);  // persistent grids of one-wave workgroups
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
-    c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 12, 1, 64);
+    c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 1, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
