@@ -484,6 +484,10 @@ struct gpuart_hip_ctx {
     bool have_camera = false, have_scene = false;
     float4 *d_nodes = nullptr, *d_prims = nullptr;
     uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow
+    uint4 *d_spill2 = nullptr;     ///< the same for kernels on the second stream
+    hipStream_t stream2 = nullptr; ///< Sun-shadow queries of segment s run here, beside the closest-hit queries of s+1
+    std::vector<hipEvent_t> ev_shaded, ev_shadowed;  ///< per segment: shading done (main stream) / shadow pass done (stream2)
+    int overlap = 1;
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
@@ -554,8 +558,13 @@ int ensure_segment_counters(gpuart_hip_ctx *c, uint32_t nseg) {
 int ensure_spill(gpuart_hip_ctx *c) {
     const uint32_t levels = c->max_depth > GD_RING ? c->max_depth - GD_RING : 0;
     if (c->d_spill && c->spill_levels >= levels) return 0;
-    if (c->d_spill) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_spill); c->d_spill = nullptr; }
+    if (c->d_spill) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(c->d_spill); (void)hipFree(c->d_spill2);
+        c->d_spill = c->d_spill2 = nullptr;
+    }
     HIP_TRY(hipMalloc(&c->d_spill, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4)));
+    HIP_TRY(hipMalloc(&c->d_spill2, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4)));
     c->spill_levels = levels;
     return 0;
 }
@@ -594,19 +603,21 @@ int fold_timings(gpuart_hip_ctx *c) {
     return 0;
 }
 
-int begin_timed(gpuart_hip_ctx *c, TimedLaunch &t, int cls) {
+int begin_timed(gpuart_hip_ctx *c, TimedLaunch &t, int cls, hipStream_t stream = nullptr) {
+    if (!stream) stream = c->stream;
     t.cls = cls;
     t.start = t.stop = nullptr;
     if (c->timing_level < 1) return 0;
     if (c->pending.size() >= 4096) { int r = fold_timings(c); if (r) return r; }
     if (!c->free_events.empty()) { t = c->free_events.back(); c->free_events.pop_back(); t.cls = cls; }
     else { HIP_TRY(hipEventCreate(&t.start)); HIP_TRY(hipEventCreate(&t.stop)); }
-    HIP_TRY(hipEventRecord(t.start, c->stream));
+    HIP_TRY(hipEventRecord(t.start, stream));
     return 0;
 }
-int end_timed(gpuart_hip_ctx *c, TimedLaunch &t) {
+int end_timed(gpuart_hip_ctx *c, TimedLaunch &t, hipStream_t stream = nullptr) {
     if (!t.start) return 0;
-    HIP_TRY(hipEventRecord(t.stop, c->stream));
+    if (!stream) stream = c->stream;
+    HIP_TRY(hipEventRecord(t.stop, stream));
     c->pending.push_back(t);
     return 0;
 }
@@ -768,18 +779,20 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     gpuart_hip_ctx *c = new (std::nothrow) gpuart_hip_ctx();
     if (!c) return fail(GPUART_HIP_ERR_DEVICE, "out of host memory");
     c->device = device;
-    c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     auto env_u32 = [](const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
         const char *v = getenv(name);
         if (!v) return dflt;
         long x = strtol(v, nullptr, 10);
         return (uint32_t)std::min<long>(hi, std::max<long>(lo, x));
     };
+    c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 12, 1, 32);  // persistent grids of one-wave workgroups
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 1, 1, 64);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
+    c->overlap = (int)env_u32("GPUART_HIP_OVERLAP", 1, 0, 1);
     if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return fail(GPUART_HIP_ERR_DEVICE, "counter allocation failed");
@@ -794,7 +807,10 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_pathmem, c->pb.counters};
+    for (auto e : c->ev_shaded) (void)hipEventDestroy(e);
+    for (auto e : c->ev_shadowed) (void)hipEventDestroy(e);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_spill, c->d_spill2, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_pathmem, c->pb.counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -911,7 +927,14 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
     const bool refwork = c->mode == 1;
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots / BLOCK));
+    while (c->ev_shaded.size() < nseg) {
+        hipEvent_t e1, e2;
+        HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        c->ev_shaded.push_back(e1); c->ev_shadowed.push_back(e2);
+    }
     for (int j = 0; j < npaths; j++) {
+        int shadow_pending = -1;
         HIP_TRY(hipMemsetAsync(c->pb.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), c->stream));
         k_gen<<<sgrid, BLOCK, 0, c->stream>>>(c->frame, *p, seed, j, npaths, b, c->d_accum);
         for (uint32_t seg = 0; seg < nseg; seg++) {
@@ -921,15 +944,32 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
             if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
             else k_trace<false, false, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
             if (detail && (r = end_timed(c, tt))) return r;
+            if (shadow_pending >= 0) {  // the previous segment's shadow pass updates pathColor, which shading reads
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shadowed[shadow_pending], 0));
+                shadow_pending = -1;
+            }
             if (refwork) k_shade<true><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
             else k_shade<false><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
             if (p->sunEnabled == 1) {
-                if (detail && (r = begin_timed(c, tt, 1))) return r;
-                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
-                else k_trace<true, true, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
-                if (detail && (r = end_timed(c, tt))) return r;
+                // The Sun-shadow queries of this segment run on the second stream, beside the closest-hit queries
+                // of the next segment (independent data); the next shading kernel waits for them.
+                hipStream_t ss = c->overlap ? c->stream2 : c->stream;
+                uint4 *sspill = c->overlap ? c->d_spill2 : c->d_spill;
+                if (c->overlap) {
+                    HIP_TRY(hipEventRecord(c->ev_shaded[seg], c->stream));
+                    HIP_TRY(hipStreamWaitEvent(ss, c->ev_shaded[seg], 0));
+                }
+                if (detail && (r = begin_timed(c, tt, 1, ss))) return r;
+                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, sspill, c->d_counters, c->tune);
+                else k_trace<true, true, false><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, sspill, c->d_counters, c->tune);
+                if (detail && (r = end_timed(c, tt, ss))) return r;
+                if (c->overlap) {
+                    HIP_TRY(hipEventRecord(c->ev_shadowed[seg], ss));
+                    shadow_pending = (int)seg;
+                }
             }
         }
+        if (shadow_pending >= 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shadowed[shadow_pending], 0));
         HIP_TRY(hipGetLastError());
     }
     return end_timed(c, t);
