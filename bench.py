@@ -187,7 +187,7 @@ def main():
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
+        cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box grants a 16-core CPU share per GPU
         otree, _ = O.build_bvh(S.scene_d())
         c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
         sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
