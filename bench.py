@@ -27,33 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from gpuart_amd import binding as B  # noqa: E402
+from gpuart_amd import sharding  # noqa: E402
 from gpuart_amd import synth_scenes as S  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 W, H = 1920, 1080
 MAX_SEGMENTS = 8
-
-
-def band_tile(rank, world, height):
-    """Contiguous row band of rank `rank` (heights differ by at most 8 rows; multiples of 8)."""
-    rows8 = (height + 7) // 8
-    lo = (rows8 * rank) // world * 8
-    hi = min(height, (rows8 * (rank + 1)) // world * 8) if rank < world - 1 else height
-    return lo, hi - lo
-
-
-def balanced_bands(world, height, cost_rows):
-    """Splits rows into `world` contiguous bands of roughly equal COST (cost_rows = per-row cost estimate
-    from a cheap probe pass), so that sky rows and mesh rows are balanced across ranks."""
-    c = np.cumsum(np.asarray(cost_rows, np.float64))
-    total = c[-1]
-    cuts = [0]
-    for r in range(1, world):
-        y = int(np.searchsorted(c, total * r / world))
-        y = max(cuts[-1] + 8, min(height - 8 * (world - r), (y + 4) // 8 * 8))
-        cuts.append(y)
-    cuts.append(height)
-    return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(world)]
 
 
 def main():
@@ -62,6 +41,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="rank 0 also renders the whole frame alone and checks the gathered frame against it bit for bit")
     args = ap.parse_args()
 
     import torch
@@ -69,12 +50,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # GPUART_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share GPUs,
+    # the exchange is staged through host memory); the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("GPUART_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where exchanged tensors live
     torch.cuda.set_device(dev)
 
     # ---- scene + renderer (gpuart::Renderer API; scene build is not part of the timed region) ----
@@ -94,11 +83,7 @@ def main():
     if world > 1:
         # every rank renders the probe identically (deterministic), so no communication is needed
         r.render_direct()
-        probe = r.read_direct()[..., :3]
-        # cost proxy: pixels that hit geometry cost ~10x sky pixels
-        sky = np.abs(probe - probe[-1:, :, :]).sum(-1) < 1e-3
-        cost_rows = np.where(sky, 1.0, 10.0).sum(1)
-        bands = balanced_bands(world, H, cost_rows)
+        bands = sharding.balanced_bands(world, H, sharding.cost_rows_from_probe(r.read_direct()[..., :3]))
         y0, th = bands[rank]
         assert r.set_tile(0, y0, W, th)
     else:
@@ -121,7 +106,7 @@ def main():
     cnt = be.counters(reset=True)
     be.set_mode(0)
     counts = torch.tensor([cnt.rays, cnt.nodes, cnt.prim_tests[0], cnt.prim_tests[1], cnt.prim_tests[2], cnt.prim_tests[3],
-                           cnt.segments, cnt.algorithmic_bytes() + 32 * W * th * K], dtype=torch.float64, device=dev)
+                           cnt.segments, cnt.algorithmic_bytes() + 32 * W * th * K], dtype=torch.float64, device=xdev)
     my_alg_bytes = float(counts[7])
     if dist is not None:
         dist.all_reduce(counts)
@@ -130,7 +115,7 @@ def main():
     # ---- warm-up (untimed), then EXACTLY K timed passes ----
     r.set_seed(5489)
     gather_buf = torch.empty((th, W, 4), dtype=torch.float32, device=dev)
-    full = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if (dist is not None and rank == 0) else None
+    full = torch.empty((H, W, 4), dtype=torch.float32, device=xdev) if (dist is not None and rank == 0) else None
     run_passes(Wm)
     be.finish()
     r.set_seed(5489)
@@ -146,13 +131,7 @@ def main():
         # RCCL gather of the normalised radiance tiles to rank 0 (bands differ in height -> send/recv)
         be.export(1, gather_buf.data_ptr(), float(K))
         be.finish()
-        if rank == 0:
-            full[y0:y0 + th].copy_(gather_buf)
-            reqs = [dist.irecv(full[b0:b0 + bh], src=s) for s, (b0, bh) in enumerate(bands) if s != 0]
-            for q in reqs:
-                q.wait()
-        else:
-            dist.isend(gather_buf, dst=0).wait()
+        sharding.gather_bands(dist, gather_buf.to(xdev), bands, rank, full)
     be.finish()
     torch.cuda.synchronize()
     if dist is not None:
@@ -161,7 +140,7 @@ def main():
     pass_ms, passes = be.kernel_time(0, reset=True)
     kernel_ms, launches = be.kernel_time(1, reset=True)
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
 
@@ -169,6 +148,16 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+
+    if args.verify_gather and dist is not None:
+        assert r.set_tile(0, 0, W, H)
+        r.set_seed(5489)
+        run_passes(K)
+        whole = r.read_radiance(True)
+        got = full.cpu().numpy()
+        same = (got[..., :3].view(np.uint32) == whole[..., :3].view(np.uint32)).all()
+        print("verify-gather: gathered %d bands %s == single-rank frame: %s" % (world, bands, bool(same)), file=sys.stderr)
+        assert same, "gathered frame differs from the single-rank frame"
 
     mrays = rays / elapsed / 1e6
     # dominant kernel = k_trace (all BVH queries: closest-hit + Sun shadow launches); its launches of the K timed
