@@ -159,33 +159,40 @@ GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F
     if (pos < GD_VISIBILITY_OFFSET) pos = -1;
 }
 
-/// Ray/AABB entry test (reference IntersectsAABB, shaders/bvh_intersection.glsl:229-354), written
-/// without branches: the same six plane parameters, the same face-bounds checks (inclusive), the same
-/// running minimum, combined with selects. Returns false on a miss; pos = -1 when the origin is inside
-/// (inclusive), else the smallest non-negative plane parameter whose hit point lies within the face.
-GD_FN bool within(float v, float lo, float hi) { return v >= lo && v <= hi; }
+/// Ray/AABB entry test (reference IntersectsAABB, shaders/bvh_intersection.glsl:229-354) without branches
+/// and almost without scalar mask arithmetic: each of the six faces yields a candidate parameter that is
+/// either its plane parameter k (when k >= 0 and the hit point lies within the face, bounds inclusive) or
+/// +inf; the result is the minimum candidate, exactly the running minimum of the reference.
+///   * `v within [lo,hi]` is evaluated as med3(v, lo, hi) == v, which equals (v >= lo && v <= hi) for every
+///     box with lo <= hi (the uploader replaces inverted / NaN boxes, which the reference can never hit, by an
+///     unreachable point box); +-0 and NaN behave like the two comparisons.
+///   * the reference's `rdir.c != 0` guards need no code: with rdiv.c = +-inf the plane parameter is +-inf or
+///     NaN, and then either `k >= 0` fails or the hit point is +-inf/NaN and fails the face check.
+/// Returns false on a miss; pos = -1 when the origin is inside (inclusive).
+GD_FN bool within(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi) == v; }
+
+GD_FN float face_candidate(float k, float a0, float a1, float lo_a, float hi_a, float b0, float b1, float lo_b, float hi_b) {
+    const float INF = __builtin_inff();
+    const float a = a0 + k * a1, b = b0 + k * b1;
+    float c = (k >= 0) ? k : INF;
+    c = within(a, lo_a, hi_a) ? c : INF;
+    c = within(b, lo_b, hi_b) ? c : INF;
+    return c;
+}
 
 GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos) {
     const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
-    float best = 1.0e+19f;
-    bool hit = false;
-#define GD_FACE(NZ, K, A0, B0, A1, B1, LOA, HIA, LOB, HIB)                                        \
-    {                                                                                             \
-        const float k = (K);                                                                      \
-        const float a = (A0) + k * (A1), b = (B0) + k * (B1);                                     \
-        const bool ok = (NZ) & (k >= 0) & within(a, LOA, HIA) & within(b, LOB, HIB);              \
-        hit |= ok;                                                                                \
-        best = (ok & (k < best)) ? k : best;                                                      \
-    }
-    const bool nx = r.d.x != 0, ny = r.d.y != 0, nz = r.d.z != 0;
-    GD_FACE(nx, (bmin.x - r.o.x) * rdiv.x, r.o.y, r.o.z, r.d.y, r.d.z, bmin.y, bmax.y, bmin.z, bmax.z)
-    GD_FACE(nx, (bmax.x - r.o.x) * rdiv.x, r.o.y, r.o.z, r.d.y, r.d.z, bmin.y, bmax.y, bmin.z, bmax.z)
-    GD_FACE(ny, (bmin.y - r.o.y) * rdiv.y, r.o.x, r.o.z, r.d.x, r.d.z, bmin.x, bmax.x, bmin.z, bmax.z)
-    GD_FACE(ny, (bmax.y - r.o.y) * rdiv.y, r.o.x, r.o.z, r.d.x, r.d.z, bmin.x, bmax.x, bmin.z, bmax.z)
-    GD_FACE(nz, (bmin.z - r.o.z) * rdiv.z, r.o.x, r.o.y, r.d.x, r.d.y, bmin.x, bmax.x, bmin.y, bmax.y)
-    GD_FACE(nz, (bmax.z - r.o.z) * rdiv.z, r.o.x, r.o.y, r.d.x, r.d.y, bmin.x, bmax.x, bmin.y, bmax.y)
-#undef GD_FACE
-    pos = inside ? -1.0f : best;
+    const float c0 = face_candidate((bmin.x - r.o.x) * rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c1 = face_candidate((bmax.x - r.o.x) * rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c2 = face_candidate((bmin.y - r.o.y) * rdiv.y, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c3 = face_candidate((bmax.y - r.o.y) * rdiv.y, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c4 = face_candidate((bmin.z - r.o.z) * rdiv.z, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y);
+    const float c5 = face_candidate((bmax.z - r.o.z) * rdiv.z, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y);
+    const float best = fminf(fminf(fminf(c0, c1), fminf(c2, c3)), fminf(c4, c5));
+    // the reference starts its running minimum at 1e19 and only lowers it with `k < pos`: a face whose k is
+    // >= 1e19 still counts as an intersection but leaves pos at 1e19
+    const bool hit = best < __builtin_inff();
+    pos = inside ? -1.0f : fminf(best, 1.0e+19f);
     return inside | hit;
 }
 
@@ -221,7 +228,7 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &close
 // entries (closest to the root, popped last) are the ones spilled, so spills are rare; any tree depth
 // up to the reference's 1024 levels works without a separate code path.
 #ifndef GD_RING
-#define GD_RING 16
+#define GD_RING 8
 #endif
 
 struct StackEntry {

@@ -139,8 +139,11 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, float4 
 // A lane that finishes its ray takes the next one from the queue (wave-local chunk, one atomic per
 // FETCH_CHUNK rays), so all 64 lanes keep traversing; box tests and leaf tests are issued as separate
 // wave-wide phases (leaf code waits until LEAF_LANES lanes need it).
+#ifndef GD_TRACE_WAVES
+#define GD_TRACE_WAVES 1
+#endif
 template <bool SHADOW, bool ANY, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
+__global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
                                                  int npaths, float4 *accum, uint4 *spill, unsigned long long *gcounters,
                                                  TraceTuning tune) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
@@ -664,6 +667,17 @@ struct Converter {
         uint32_t ref;
     };
 
+    /// A box that is inverted (min > max on some axis: e.g. a sphere with a negative radius, or the empty scene)
+    /// or holds a NaN can never be hit by the reference's comparisons. The device's box test assumes min <= max,
+    /// so such a box is replaced by a point box far outside anything a ray can reach (its entry parameter
+    /// would exceed the initial `closest` of 1e19, so it is never entered).
+    static void sanitize(Child &c) {
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok = ok && (c.bmin[k] <= c.bmax[k]);  // false for NaN too
+        if (!ok)
+            for (int k = 0; k < 3; k++) c.bmin[k] = c.bmax[k] = 3.0e+38f;
+    }
+
     /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
     /// interior lower child's record directly follows its parent's); leaves append their primitives.
     bool node(size_t addr, uint32_t depth, Child &out) {
@@ -706,6 +720,7 @@ struct Converter {
         Child L, H;
         if (!node(lo, depth + 1, L)) return false;
         if (!node(hi, depth + 1, H)) return false;
+        sanitize(L); sanitize(H);
         recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
         recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
         recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], 0);
@@ -842,6 +857,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     cv.q = quads; cv.nq = nquads;
     Converter::Child root;
     if (!cv.node(0, 0, root)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
+    Converter::sanitize(root);
     int r;
     if ((r = upload_vec(c, c->d_nodes, cv.recs))) return r;
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
