@@ -6,6 +6,7 @@
 //           fetch of one 64-byte line serves two box tests:
 //             [4r]   = { lo.bbmin.xyz, bits(lo ref) }     ref = record index of an interior child, or
 //             [4r+1] = { lo.bbmax.xyz, bits(hi ref) }           bit31 | first primitive index of a leaf child
+//                                                               (| bit30 when the leaf is one or two triangles)
 //             [4r+2] = { hi.bbmin.xyz, 0 }
 //             [4r+3] = { hi.bbmax.xyz, 0 }
 //           The root's own box and ref travel in the Scene struct.
@@ -27,6 +28,8 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #define GD_META_LEAF 0x80000000u
 
 #define GD_REF_LEAF 0x80000000u
+#define GD_REF_TRIS 0x40000000u  ///< with GD_REF_LEAF: the leaf holds only triangles, one or two of them
+#define GD_REF_INDEX 0x3fffffffu
 
 struct Scene {
     const float4 *__restrict__ recs;
@@ -148,6 +151,43 @@ GD_FN void cone_hit(const Ray &r, F3 c1, float r1, F3 ax, float axLen, float wid
     }
 }
 
+typedef float V2 __attribute__((ext_vector_type(2)));
+GD_FN V2 v2(float a, float b) { V2 r; r.x = a; r.y = b; return r; }
+
+/// Ray parameters of TWO triangles at once (lane-wise the arithmetic of triangle.glsl:50-76, including the
+/// (du+dv)*invDet form and dot3's order; the pair is carried in 2-wide vectors so that the multiplies and
+/// adds become packed instructions). Straight-line: every rejection is a term of one predicate; a rejected
+/// triangle yields -1, and so does one closer than VISIBILITY_OFFSET (bvh_intersection.glsl:216-217).
+GD_FN V2 triangle_pair_t(const Ray &r, float4 a0, float4 a1, float4 a2, float4 b0, float4 b1, float4 b2) {
+    const V2 v0x = v2(a0.x, b0.x), v0y = v2(a0.y, b0.y), v0z = v2(a0.z, b0.z);
+    const V2 e1x = v2(a1.x, b1.x), e1y = v2(a1.y, b1.y), e1z = v2(a1.z, b1.z);
+    const V2 e2x = v2(a2.x, b2.x), e2y = v2(a2.y, b2.y), e2z = v2(a2.z, b2.z);
+    const V2 dx = v2(r.d.x, r.d.x), dy = v2(r.d.y, r.d.y), dz = v2(r.d.z, r.d.z);
+    // pvec = cross(rdir, edge2)
+    const V2 px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+    const V2 det = (e1z * pz + e1y * py) + e1x * px;
+    V2 inv; inv.x = 1 / det.x; inv.y = 1 / det.y;
+    const V2 tx = v2(r.o.x, r.o.x) - v0x, ty = v2(r.o.y, r.o.y) - v0y, tz = v2(r.o.z, r.o.z) - v0z;
+    const V2 du = (tz * pz + ty * py) + tx * px;
+    const V2 u = du * inv;
+    // qvec = cross(tvec, edge1)
+    const V2 qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    const V2 dv = (dz * qz + dy * qy) + dx * qx;
+    const V2 v = dv * inv;
+    const V2 w = (du + dv) * inv;
+    const V2 t = ((e2z * qz + e2y * qy) + e2x * qx) * inv;
+    V2 out;
+    {
+        bool ok = !(fabsf(det.x) < 1.0e-10f) & !(u.x < 0) & !(u.x > 1) & !(v.x < 0) & !(w.x > 1) & !(t.x < GD_VISIBILITY_OFFSET);
+        out.x = ok ? t.x : -1.0f;
+    }
+    {
+        bool ok = !(fabsf(det.y) < 1.0e-10f) & !(u.y < 0) & !(u.y > 1) & !(v.y < 0) & !(w.y > 1) & !(t.y < GD_VISIBILITY_OFFSET);
+        out.y = ok ? t.y : -1.0f;
+    }
+    return out;
+}
+
 /// One primitive record against a ray (reference CheckBVHPrimitiveIntersection,
 /// shaders/bvh_intersection.glsl:125-223, including its `pos < VISIBILITY_OFFSET -> -1` cut).
 GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F3 &p, F3 &n, int &ptype) {
@@ -221,6 +261,31 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &close
     return false;
 }
 
+/// Leaf that holds one or two triangles (the common case of triangle meshes: the reference builds leaves of at
+/// most two primitives): both records are fetched and tested together. With a single triangle the second slot
+/// re-reads the first record; a repeated equal parameter can never replace the hit (`pos < closest` is strict).
+template <bool ANY_HIT, bool COUNT>
+GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+    const float4 *pa = sc.prims + 3 * (size_t)first;
+    float4 a0 = pa[0];
+    const uint32_t count = __float_as_uint(a0.w) >> 2;
+    const float4 *pb = count > 1 ? pa + 3 : pa;
+    float4 a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+    if (COUNT) wc->prims[P_TRIANGLE] += count;
+    V2 t = triangle_pair_t(r, a0, a1, a2, b0, b1, b2);
+    if (t.x > 0 && t.x < closest) {
+        closest = t.x;
+        hit_prim = first;
+        if (ANY_HIT) return true;
+    }
+    if (t.y > 0 && t.y < closest) {
+        closest = t.y;
+        hit_prim = first + 1;  // only reachable with count == 2
+        if (ANY_HIT) return true;
+    }
+    return false;
+}
+
 // ---- traversal stack: short per-lane ring in LDS + spill to global memory -------------------------
 // Entry = (upper child's ref, parent's box-entry parameter, the child's own box-entry parameter).
 // Entries [base, sp) live in the LDS ring (slot = index % RING, one column per
@@ -280,7 +345,7 @@ struct TravStack {
 /// hit (same value: the test is a pure function of node and ray). The upper child's box is tested when
 /// its parent's record is fetched (both boxes share one 64-byte record) and the result waits on the
 /// stack; whether it is *used* is decided exactly where the reference decides it, at pop time.
-enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2 };
+enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2, TRAV_LEAF_TRIS = 3 };
 
 #define GD_ENTRY_MISS 3.0e+38f  // stack marker: the upper child's box is not hit at all
 
@@ -295,8 +360,8 @@ struct Trav {
 /// Enters a child whose box test passed: a leaf waits for its primitive tests, an interior child for its record.
 GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
     if (ref & GD_REF_LEAF) {
-        t.node = ref & ~GD_REF_LEAF;
-        t.state = TRAV_LEAF;
+        t.node = ref & GD_REF_INDEX;
+        t.state = (ref & GD_REF_TRIS) ? TRAV_LEAF_TRIS : TRAV_LEAF;
     } else {
         t.node = ref;
         t.entry = entry;
@@ -338,6 +403,10 @@ template <bool COUNT>
 GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc) {
     const float4 *rec = sc.recs + 4 * (size_t)t.node;
     float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    // Keep the two child refs in the 16-byte loads: without this the compiler narrows the loads to 12 bytes and
+    // fetches a ref with a separate, dependent 4-byte load inside the branch that needs it (one more memory
+    // round trip per step).
+    asm volatile("" : "+v"(q0.w), "+v"(q1.w));
     float el, eh;
     bool hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
     bool hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
@@ -354,10 +423,13 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     trav_pop<COUNT>(t, st, wc);
 }
 
-/// Tests the primitives of the pending leaf, then pops. Precondition: state == LEAF.
+/// Tests the primitives of the pending leaf, then pops. Precondition: state == LEAF or LEAF_TRIS.
 template <bool ANY_HIT, bool COUNT>
 GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
-    if (leaf_test<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc) && ANY_HIT) {
+    bool stop;
+    if (t.state == TRAV_LEAF_TRIS) stop = leaf_test_tris<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc);
+    else stop = leaf_test<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc);
+    if (stop && ANY_HIT) {
         t.state = TRAV_DONE;
         return;
     }

@@ -201,12 +201,13 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
         // ---- traverse until enough lanes have finished
         for (;;) {
             if (slot != SLOT_INVALID && t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, r, rdiv, t, st, COUNT ? &wc : nullptr);
-            unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && t.state == TRAV_LEAF);
+            unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
             if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
-                if (slot != SLOT_INVALID && t.state == TRAV_LEAF) trav_step_leaf<ANY, COUNT>(sc, r, t, st, COUNT ? &wc : nullptr);
+                if (slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS))
+                    trav_step_leaf<ANY, COUNT>(sc, r, t, st, COUNT ? &wc : nullptr);
                 descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
-                at_leaf = __ballot(slot != SLOT_INVALID && t.state == TRAV_LEAF);
+                at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             }
             unsigned long long busy = descending | at_leaf;
             if (!busy) break;
@@ -691,13 +692,15 @@ struct Converter {
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
             uint32_t first = (uint32_t)(prims.size() / 3);
-            if (first >= 0x80000000u) { err = "too many primitives"; return false; }
+            if (first >= 0x3ffffff0u) { err = "too many primitives"; return false; }
             size_t a = addr + 3;
             static const int LEN[4] = {1, 2, 3, 4};
+            bool all_tris = n >= 1 && n <= 2;
             for (uint32_t i = 0; i < n; i++) {
                 if (a + 1 > nq) { err = "primitive header out of range"; return false; }
                 uint32_t type = bits(q[4 * a]);
                 if (type > 3) { err = "unknown primitive type"; return false; }
+                if (type != P_TRIANGLE) all_tris = false;
                 if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
                 float4 rec[3];
                 pack_prim(type, q + 4 * (a + 1), rec);
@@ -708,14 +711,14 @@ struct Converter {
             if (n == 0) {  // empty leaf (empty scene): one dummy record with count 0
                 prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
             }
-            out.ref = GD_REF_LEAF | first;
+            out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS : 0u) | first;
             return true;
         }
         uint32_t lo = bits(b[9]), hi = bits(b[10]);
         if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
         if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
         const size_t r = recs.size() / 4;
-        if (r >= 0x80000000u) { err = "too many nodes"; return false; }
+        if (r >= 0x3ffffff0u) { err = "too many nodes"; return false; }
         recs.resize(recs.size() + 4);
         Child L, H;
         if (!node(lo, depth + 1, L)) return false;
