@@ -500,6 +500,7 @@ struct gpuart_hip_ctx {
     void *d_pathmem = nullptr;
     uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
+    uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
     uint32_t max_depth = 0;
@@ -632,6 +633,7 @@ struct Converter {
     size_t nq;
     std::vector<float4> recs, prims;
     size_t num_nodes = 0;
+    uint32_t type_mask = 0;
     uint32_t max_depth = 0;
     std::string err;
 
@@ -701,6 +703,7 @@ struct Converter {
                 uint32_t type = bits(q[4 * a]);
                 if (type > 3) { err = "unknown primitive type"; return false; }
                 if (type != P_TRIANGLE) all_tris = false;
+                type_mask |= 1u << type;
                 if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
                 float4 rec[3];
                 pack_prim(type, q + 4 * (a + 1), rec);
@@ -866,6 +869,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
     c->root_ref = root.ref;
+    c->type_mask = cv.type_mask;
     c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
     c->max_depth = cv.max_depth;
@@ -912,16 +916,30 @@ int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
     return 0;
 }
 
-/// Upper bound on the number of segments any path can have: colorWeight's blue channel is multiplied by
-/// at most 0.35 per segment (path_tracing.glsl:123-126), and the loop stops once a channel is <= minWeight.
-static uint32_t segment_bound(const gpuart_params *p) {
+/// Upper bound on the number of segments any path can have. colorWeight is multiplied per segment by the albedo
+/// of the primitive type that was hit (path_tracing.glsl:123-126,204) and the loop stops as soon as ANY channel
+/// is <= minWeight, so channel c survives at most as long as (largest albedo.c among the primitive types present
+/// in the scene)^n > minWeight; the bound is the smallest such n over the channels (+1 when a product comes
+/// within 1e-4 of minWeight, where fp32 rounding of a mixed product could differ). Kernels for segments beyond
+/// the bound would find empty queues; not launching them saves their fixed cost.
+static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
     if (p->maxSegments <= 0 || !(1.0f > p->minWeight)) return 0;
     uint32_t n = (uint32_t)p->maxSegments;
-    if (p->minWeight > 0) {
-        double bound = std::ceil(std::log((double)p->minWeight) / std::log(0.36)) + 2;  // 0.36 > 0.35: safe side
-        if (bound < (double)n) n = (uint32_t)bound;
+    if (!(p->minWeight > 0)) return n;
+    static const float ALBEDO[4][3] = {{0.65f, 0.4f, 0.35f}, {0.1f, 0.2f, 0.1f}, {0.3f, 0.3f, 0.3f}, {0.3f, 0.3f, 0.3f}};
+    // The user sphere shades as a sphere, and even with radius 0 (= "disabled") its quadratic can report a hit through
+    // rounding (sphere.glsl:47-52), so the sphere albedo always takes part in the bound.
+    const uint32_t types = c->type_mask | 1u;
+    uint32_t bound = n;
+    for (int ch = 0; ch < 3; ch++) {
+        float a = 0;
+        for (int t = 0; t < 4; t++) if (types & (1u << t)) a = std::max(a, ALBEDO[t][ch]);
+        float w = 1.0f;
+        uint32_t k = 0;
+        while (k < n && w > p->minWeight * 1.0001f) { w *= a; k++; }
+        bound = std::min(bound, k);
     }
-    return n;
+    return std::max<uint32_t>(bound, 1);
 }
 
 int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float randSeed[4], int npaths) {
@@ -941,7 +959,7 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
         HIP_TRY(hipGetLastError());
         return end_timed(c, t);
     }
-    const uint32_t nseg = segment_bound(p);
+    const uint32_t nseg = segment_bound(c, p);
     if ((r = ensure_segment_counters(c, nseg))) return r;
     const bool refwork = c->mode == 1;
     const dim3 pgrid(c->grid_waves);
