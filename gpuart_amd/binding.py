@@ -68,6 +68,7 @@ def host_lib():
         for name in ["destroy", "is_ok", "set_primitives", "init_box", "init_dragon", "set_camera", "update_viewport",
                      "set_tile", "set_sun", "set_user_sphere", "set_max_path_segments", "set_seed", "render_direct",
                      "restart_path_tracing", "path_tracing_pass", "read_direct", "read_radiance", "finish", "backend",
+                     "save_checkpoint", "load_checkpoint",
                      "params", "scene_info"]:
             getattr(L, "gpuart_renderer_" + name).argtypes = None
         _host = L
@@ -206,6 +207,10 @@ class Backend:
         out = np.empty((th, tw, 4), np.float32)
         self._chk(self.L.gpuart_hip_read(self.ctx, C.c_int(which), _p(out), C.c_float(divide_by)))
         return out
+
+    def write(self, which, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        self._chk(self.L.gpuart_hip_write(self.ctx, C.c_int(which), _p(rgba)))
 
     def export(self, which, device_ptr, divide_by=1.0):
         self._chk(self.L.gpuart_hip_export(self.ctx, C.c_int(which), C.c_void_p(device_ptr), C.c_float(divide_by)))
@@ -372,6 +377,8 @@ class Renderer:
         return out
 
     def finish(self): return bool(self.L.gpuart_renderer_finish(self.h))
+    def save_checkpoint(self, path): return bool(self.L.gpuart_renderer_save_checkpoint(self.h, path.encode()))
+    def load_checkpoint(self, path): return bool(self.L.gpuart_renderer_load_checkpoint(self.h, path.encode()))
 
     def params(self):
         p = Params()

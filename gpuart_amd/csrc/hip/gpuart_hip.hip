@@ -1040,6 +1040,14 @@ int gpuart_hip_read(gpuart_hip_ctx *c, int which, float *rgba_host, float divide
     return 0;
 }
 
+int gpuart_hip_write(gpuart_hip_ctx *c, int which, const float *rgba_host) {
+    if (!c || !rgba_host || which != 1 || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->d_accum, rgba_host, c->tile_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int gpuart_hip_finish(gpuart_hip_ctx *c) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     HIP_TRY(hipSetDevice(c->device));

@@ -152,6 +152,8 @@ int gpuart_renderer_read_radiance(gpuart_renderer *r, float *rgba, int normalize
     return r->impl.ReadRadiance(rgba, normalized != 0) ? 1 : 0;
 }
 int gpuart_renderer_finish(gpuart_renderer *r) { return r->impl.Finish() ? 1 : 0; }
+int gpuart_renderer_save_checkpoint(gpuart_renderer *r, const char *path) { return r->impl.SaveCheckpoint(path) ? 1 : 0; }
+int gpuart_renderer_load_checkpoint(gpuart_renderer *r, const char *path) { return r->impl.LoadCheckpoint(path) ? 1 : 0; }
 gpuart_hip_ctx *gpuart_renderer_backend(gpuart_renderer *r) { return r->impl.GetBackend(); }
 void gpuart_renderer_params(gpuart_renderer *r, gpuart_params *out) { *out = r->impl.MakeParams(); }
 void gpuart_renderer_scene_info(gpuart_renderer *r, uint64_t *nodes, uint64_t *prims, unsigned *depth) {

@@ -58,6 +58,8 @@ unsigned gpuart_renderer_path_tracing_pass(gpuart_renderer *r);
 int gpuart_renderer_read_direct(gpuart_renderer *r, float *rgba);
 int gpuart_renderer_read_radiance(gpuart_renderer *r, float *rgba, int normalized);
 int gpuart_renderer_finish(gpuart_renderer *r);
+int gpuart_renderer_save_checkpoint(gpuart_renderer *r, const char *path);
+int gpuart_renderer_load_checkpoint(gpuart_renderer *r, const char *path);
 gpuart_hip_ctx *gpuart_renderer_backend(gpuart_renderer *r);
 void gpuart_renderer_params(gpuart_renderer *r, gpuart_params *out);
 void gpuart_renderer_scene_info(gpuart_renderer *r, uint64_t *nodes, uint64_t *prims, unsigned *depth);

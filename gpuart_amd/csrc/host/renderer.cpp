@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <chrono>
 #include <iomanip>
+#include <cstring>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 
 #include "utils.h"
 
@@ -79,6 +82,7 @@ bool Renderer::UpdateViewportSize(unsigned width, unsigned height) {
     Viewport.width = width;
     Viewport.height = height;
     if (!Check(gpuart_hip_resize(Backend, width, height), "allocating per-pixel buffers")) return IsOK = false;
+    Tile.x = Tile.y = 0; Tile.w = width; Tile.h = height;
     if (!SetCamera(CurrentCamera)) IsOK = false;
     return IsOK;
 }
@@ -86,6 +90,7 @@ bool Renderer::UpdateViewportSize(unsigned width, unsigned height) {
 bool Renderer::SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h) {
     if (!Backend) return false;
     if (!Check(gpuart_hip_set_tile(Backend, x0, y0, w, h), "setting the tile")) return false;
+    Tile.x = x0; Tile.y = y0; Tile.w = w; Tile.h = h;
     ResetPathTracing();
     return true;
 }
@@ -210,6 +215,72 @@ bool Renderer::ReadRadiance(float *rgba, bool normalized) {
     // the division is the reference's ptracingNormalize program (shaders/pt_normalize.glsl:44-47)
     const float div = normalized && PathTracing.numPathsRendered ? (float)PathTracing.numPathsRendered : 1.0f;
     return IsOK && Check(gpuart_hip_read(Backend, 1, rgba, div), "reading the radiance accumulator");
+}
+
+// ---- checkpoint / resume ---------------------------------------------------------------------------------------------
+namespace {
+const char CK_MAGIC[8] = {'G', 'P', 'U', 'A', 'R', 'T', 'C', 'K'};
+struct CkHeader {
+    char magic[8];
+    uint32_t version, width, height, tileX, tileY, tileW, tileH;
+    uint32_t numPathsRendered, pathsPerPixel, pathsPerPass, maxPathSegments;
+    float minWeight;
+    uint32_t rngTextBytes;
+};
+}  // namespace
+
+bool Renderer::SaveCheckpoint(const char *fileName) {
+    if (!IsOK) return false;
+    std::vector<float> acc((size_t)Tile.w * Tile.h * 4);
+    if (!ReadRadiance(acc.data(), false)) return false;
+    std::ostringstream rng;
+    rng << RndGen;  // the full mt19937 state, as text
+    const std::string rngText = rng.str();
+    CkHeader h{};
+    memcpy(h.magic, CK_MAGIC, 8);
+    h.version = 1; h.width = Viewport.width; h.height = Viewport.height;
+    h.tileX = Tile.x; h.tileY = Tile.y; h.tileW = Tile.w; h.tileH = Tile.h;
+    h.numPathsRendered = PathTracing.numPathsRendered; h.pathsPerPixel = PathTracing.pathsPerPixel;
+    h.pathsPerPass = PathTracing.pathsPerPass; h.maxPathSegments = MaxPathSegments; h.minWeight = MinWeight;
+    h.rngTextBytes = (uint32_t)rngText.size();
+    std::ofstream f(fileName, std::ios::binary);
+    f.write((const char *)&h, sizeof h);
+    f.write(rngText.data(), (std::streamsize)rngText.size());
+    f.write((const char *)acc.data(), (std::streamsize)(acc.size() * sizeof(float)));
+    return f.good();
+}
+
+bool Renderer::LoadCheckpoint(const char *fileName) {
+    if (!IsOK) return false;
+    std::ifstream f(fileName, std::ios::binary);
+    CkHeader h{};
+    f.read((char *)&h, sizeof h);
+    if (!f.good() || memcmp(h.magic, CK_MAGIC, 8) != 0 || h.version != 1) {
+        std::cerr << "Renderer: \"" << fileName << "\" is not a checkpoint." << std::endl;
+        return false;
+    }
+    if (h.width != Viewport.width || h.height != Viewport.height || h.tileX != Tile.x || h.tileY != Tile.y ||
+        h.tileW != Tile.w || h.tileH != Tile.h || h.rngTextBytes > (1u << 20)) {
+        std::cerr << "Renderer: checkpoint does not match the current viewport / tile." << std::endl;
+        return false;
+    }
+    std::string rngText(h.rngTextBytes, '\0');
+    f.read(&rngText[0], (std::streamsize)rngText.size());
+    std::vector<float> acc((size_t)Tile.w * Tile.h * 4);
+    f.read((char *)acc.data(), (std::streamsize)(acc.size() * sizeof(float)));
+    if (!f.good()) return false;
+    std::istringstream rng(rngText);
+    std::mt19937 gen;
+    rng >> gen;
+    if (rng.fail()) return false;
+    if (!Check(gpuart_hip_write(Backend, 1, acc.data()), "restoring the radiance accumulator")) return false;
+    RndGen = gen;
+    PathTracing.numPathsRendered = h.numPathsRendered;
+    PathTracing.pathsPerPixel = h.pathsPerPixel;
+    PathTracing.pathsPerPass = h.pathsPerPass;
+    MaxPathSegments = h.maxPathSegments;
+    MinWeight = h.minWeight;
+    return true;
 }
 
 bool Renderer::Finish() { return Backend && Check(gpuart_hip_finish(Backend), "waiting for the device"); }

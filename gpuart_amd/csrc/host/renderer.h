@@ -91,7 +91,14 @@ public:
     /// Restricts this renderer to a tile of the frame (screen-space sharding across GPUs).
     bool SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h);
     unsigned GetNumPathsRendered() const { return PathTracing.numPathsRendered; }
+    /// Progressive-render checkpoint: accumulator + pass counters + RNG state of this tile.
+    /// After LoadCheckpoint the following passes are bit-identical to those of the uninterrupted run. The
+    /// scene, camera, lighting and viewport/tile must have been set up as they were when saving.
+    bool SaveCheckpoint(const char *fileName);
+    bool LoadCheckpoint(const char *fileName);
     gpuart_hip_ctx *GetBackend() const { return Backend; }
+    unsigned GetTileWidth() const { return Tile.w; }
+    unsigned GetTileHeight() const { return Tile.h; }
     const BoundingVolumesHierarchy &GetBVH() const { return Tree; }
     gpuart_params MakeParams() const;
 
@@ -102,6 +109,7 @@ private:
     gpuart_hip_ctx *Backend = nullptr;
     BoundingVolumesHierarchy Tree;
     struct { unsigned width, height; } Viewport{0, 0};
+    struct { unsigned x, y, w, h; } Tile{0, 0, 0, 0};  ///< the part of the frame this renderer owns
     Camera CurrentCamera;
     struct { float azimuth, altitude; bool directLightingEnabled; } Lighting;
     struct { Vec3f pos; float radius, emittance; uint32_t flags; } UserSphere;

@@ -99,6 +99,10 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *ctx, const gpuart_params *p, const float 
  * rgba_host receives tw*th*4 floats. Synchronises the stream. */
 int gpuart_hip_read(gpuart_hip_ctx *ctx, int which, float *rgba_host, float divide_by);
 
+/* The inverse of gpuart_hip_read for which = 1: replaces the path-tracing accumulator of the tile with tw*th*4 floats
+ * from the host (resuming a checkpointed progressive render; the reference has no equivalent). */
+int gpuart_hip_write(gpuart_hip_ctx *ctx, int which, const float *rgba_host);
+
 /* Same, device to device, into caller-owned device memory (for the multi-GPU gather: the caller
  * hands it to RCCL). Asynchronous on the context's stream; call gpuart_hip_finish before use. */
 int gpuart_hip_export(gpuart_hip_ctx *ctx, int which, void *rgba_device, float divide_by);

@@ -389,6 +389,32 @@ def test_empty_scene_and_single_primitive(B, be, O):
         assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "PT, %d primitives" % len(prims))
 
 
+def test_inverted_and_degenerate_boxes(B, be, O):
+    """Negative radii give inverted boxes (min > max), which the reference's comparisons can never hit; flat
+    triangles give zero-thickness boxes. Both must behave exactly like the oracle."""
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    W, H = 80, 48
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
+    prims = S.box_scene() + [(S.SPHERE, [0.3, -0.5, 0.4, -0.2]), (S.SPHERE, [-0.5, -0.6, 0.3, -0.1]),
+                             (S.DISC, [0.2, 0.2, 0.5, 0, 0, 1, -0.3]), (S.CONE, [-0.5, 0.5, 0, -0.5, 0.5, 0.4, -0.1, -0.2]),
+                             (S.TRIANGLE, [-0.8, -0.9, 0.5, 0.8, -0.9, 0.5, 0.0, -0.2, 0.5])]
+    tree, _ = B.compile_bvh(prims)
+    otree, _ = O.build_bvh(prims)
+    assert (tree.view(np.uint32) == otree.view(np.uint32)).all()
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    be.render_direct(to_params(B, P))
+    exp, _ = O.render_direct(tree, c, W, H, P)
+    assert_bits(be.read(0)[..., :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "direct")
+    acc = np.zeros((H, W, 4), np.float32)
+    be.pt_reset()
+    for k, seed in enumerate(O.randseeds(3)):
+        be.pt_pass(to_params(B, P), seed, 1)
+        O.pt_pass(tree, c, W, H, P, seed, 1, acc)
+    assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "PT")
+
+
 def test_malformed_tree_is_rejected(B, be):
     tree, _ = B.compile_bvh(S.box_scene())
     bad = tree.copy()
@@ -461,3 +487,71 @@ def test_full_size_accumulation_is_additive(B, be, O, dragon_1080p):
     be.render_direct(to_params(B, P)); d1 = be.read(0)
     be.render_direct(to_params(B, P)); d2 = be.read(0)
     np.testing.assert_array_equal(d1, d2)
+
+
+def test_checkpoint_resume_is_bit_identical(B, tmp_path):
+    """8 passes == 3 passes + SaveCheckpoint + (new Renderer) LoadCheckpoint + 5 passes, including the RNG state."""
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    W, H = 96, 64
+    prims = S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64)
+
+    def fresh():
+        r = B.Renderer(W, H, cam)
+        r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+        r.set_primitives(prims)
+        return r
+
+    r = fresh()
+    r.restart_path_tracing(1, 8)
+    for _ in range(8):
+        r.path_tracing_pass()
+    whole = r.read_radiance(False)
+    r.close()
+
+    r = fresh()
+    r.restart_path_tracing(1, 8)
+    for _ in range(3):
+        r.path_tracing_pass()
+    ck = str(tmp_path / "render.ck")
+    assert r.save_checkpoint(ck)
+    r.close()
+
+    r = fresh()
+    r.restart_path_tracing(1, 8)
+    assert r.load_checkpoint(ck)
+    done = [r.path_tracing_pass() for _ in range(6)]
+    assert done == [4, 5, 6, 7, 8, 8]
+    resumed = r.read_radiance(False)
+    assert not r.load_checkpoint(str(tmp_path / "missing.ck"))
+    r.update_viewport(W // 2, H)
+    assert not r.load_checkpoint(ck)  # viewport mismatch is refused
+    r.close()
+    np.testing.assert_array_equal(whole, resumed)
+
+
+def test_headless_cli(B, O, tmp_path):
+    """gpuart_cli (replaces the reference's GUI main loop): Box scene, direct + progressive PT, PFM/PPM output."""
+    import json, subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpuart_amd", "bin", "gpuart_cli")
+    pfm, ppm = str(tmp_path / "o.pfm"), str(tmp_path / "o.ppm")
+    W, H = 80, 60
+    out = subprocess.run([exe, "--scene", "box", "--width", str(W), "--height", str(H), "--mode", "pt", "--spp", "4",
+                          "--per-pass", "2", "--pfm", pfm, "--ppm", ppm], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["paths_per_pixel"] == 4 and info["passes"] == 2
+    raw = open(pfm, "rb").read()
+    head = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert raw.startswith(head)
+    img = np.frombuffer(raw[len(head):], np.float32).reshape(H, W, 3)
+    # the same render through the oracle: 2 passes of 2 paths, normalised by 4
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    tree, _ = O.build_bvh(S.box_scene())
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
+    acc = np.zeros((H, W, 4), np.float32)
+    for seed in O.randseeds(2):
+        O.pt_pass(tree, c, W, H, P, seed, 2, acc)
+    assert_bits(img.reshape(-1, 3), (acc[..., :3] / np.float32(4)).reshape(-1, 3), "CLI PFM vs oracle")
+    assert open(ppm, "rb").read().startswith(b"P6\n%d %d\n255\n" % (W, H))
