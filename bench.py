@@ -6,9 +6,9 @@ tracing, dragon-class scene (Scene D: 100 352-triangle mesh + floor disc), 1920x
     python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run)
 
 A "step" is one progressive pass (gpuart::Renderer::RenderPathTracingPass) over the whole frame. With
-N>1 the FIXED 1080p frame is sharded by screen-space bands across ranks (strong scaling, north_star's
-"tile scaling"); after the K timed passes every rank exports its accumulated radiance and rank 0
-gathers it over RCCL (inside the timed region).
+N>1 the FIXED 1080p frame is sharded by screen space across ranks (8-row bands dealt round-robin; strong
+scaling, north_star's "tile scaling"); after the K timed passes every rank exports its accumulated
+radiance and rank 0 gathers it over RCCL (inside the timed region).
 
 Rays are counted exactly (closest-hit queries as the reference performs them: camera, bounce and Sun
 shadow rays) by running the same K passes once, untimed, in the library's reference-work mode; the
@@ -79,15 +79,12 @@ def main():
     be = r.backend
     info = be.scene_info()
 
-    # ---- tile of this rank: contiguous bands balanced by a cheap cost probe (direct lighting) ----
+    # ---- tile of this rank: 8-row bands of the frame dealt round-robin to the ranks (balances sky / floor / mesh
+    #      rows statistically; 8x8 pixel tiles stay intact); nothing is exchanged until the final gather ----
     if world > 1:
-        # every rank renders the probe identically (deterministic), so no communication is needed
-        r.render_direct()
-        bands = sharding.balanced_bands(world, H, sharding.cost_rows_from_probe(r.read_direct()[..., :3]))
-        y0, th = bands[rank]
-        assert r.set_tile(0, y0, W, th)
+        y0, th, band, stride, my_rows = sharding.interleaved_rows(rank, world, H)
+        assert r.set_interleaved_tile(0, y0, W, th, band, stride)
     else:
-        bands = [(0, H)]
         y0, th = 0, H
 
     K, Wm = args.steps, args.warmup
@@ -131,7 +128,7 @@ def main():
         # RCCL gather of the normalised radiance tiles to rank 0 (bands differ in height -> send/recv)
         be.export(1, gather_buf.data_ptr(), float(K))
         be.finish()
-        sharding.gather_bands(dist, gather_buf.to(xdev), bands, rank, full)
+        sharding.gather_interleaved(dist, gather_buf.to(xdev), rank, world, H, full)
     be.finish()
     torch.cuda.synchronize()
     if dist is not None:
@@ -156,7 +153,7 @@ def main():
         whole = r.read_radiance(True)
         got = full.cpu().numpy()
         same = (got[..., :3].view(np.uint32) == whole[..., :3].view(np.uint32)).all()
-        print("verify-gather: gathered %d bands %s == single-rank frame: %s" % (world, bands, bool(same)), file=sys.stderr)
+        print("verify-gather: gathered %d interleaved row sets == single-rank frame: %s" % (world, bool(same)), file=sys.stderr)
         assert same, "gathered frame differs from the single-rank frame"
 
     mrays = rays / elapsed / 1e6
@@ -206,7 +203,7 @@ def main():
         "config": {"workload": "cfg3: Scene D (dragon-class, 100352 triangles + floor disc), 1920x1080, path tracing "
                                "depth 8 (MAX_PATH_SEGMENTS=8, MIN_WEIGHT=0.01), 1 path/pixel/pass, Sun direct lighting on, "
                                "benchmark camera",
-                   "frame": [W, H], "parallelism": "screen-space bands x%d" % world,
+                   "frame": [W, H], "parallelism": "8-row screen bands interleaved over %d rank(s)" % world,
                    "bvh_nodes": info["nodes"], "bvh_primitives": info["prims"], "bvh_depth": info["max_depth"],
                    "scene_device_bytes": info["device_bytes"], "scene_setup_s": round(setup_s, 3)},
         "ms_per_frame": round(elapsed / K * 1e3, 4),

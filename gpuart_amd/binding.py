@@ -66,7 +66,7 @@ def host_lib():
         L.gpuart_renderer_backend.restype = C.c_void_p
         L.gpuart_renderer_path_tracing_pass.restype = C.c_uint
         for name in ["destroy", "is_ok", "set_primitives", "init_box", "init_dragon", "set_camera", "update_viewport",
-                     "set_tile", "set_sun", "set_user_sphere", "set_max_path_segments", "set_seed", "render_direct",
+                     "set_tile", "set_interleaved_tile", "set_sun", "set_user_sphere", "set_max_path_segments", "set_seed", "render_direct",
                      "restart_path_tracing", "path_tracing_pass", "read_direct", "read_radiance", "finish", "backend",
                      "save_checkpoint", "load_checkpoint",
                      "params", "scene_info"]:
@@ -182,6 +182,11 @@ class Backend:
     def set_tile(self, x0, y0, tw, th):
         self._chk(self.L.gpuart_hip_set_tile(self.ctx, C.c_uint32(x0), C.c_uint32(y0), C.c_uint32(tw), C.c_uint32(th)))
         self.tile = (x0, y0, tw, th)
+
+    def set_tile_interleaved(self, x0, y0, tw, th_local, band_rows, band_stride):
+        self._chk(self.L.gpuart_hip_set_tile_interleaved(self.ctx, C.c_uint32(x0), C.c_uint32(y0), C.c_uint32(tw), C.c_uint32(th_local),
+                                                         C.c_uint32(band_rows), C.c_uint32(band_stride)))
+        self.tile = (x0, y0, tw, th_local)
 
     def upload_bvh(self, quads):
         quads = np.ascontiguousarray(quads, np.float32)
@@ -344,6 +349,13 @@ class Renderer:
         ok = bool(self.L.gpuart_renderer_set_tile(self.h, C.c_uint(x0), C.c_uint(y0), C.c_uint(w), C.c_uint(h)))
         if ok:
             self.tile = self.backend.tile = (x0, y0, w, h)
+        return ok
+
+    def set_interleaved_tile(self, x0, y0, w, local_rows, band_rows, band_stride):
+        ok = bool(self.L.gpuart_renderer_set_interleaved_tile(self.h, C.c_uint(x0), C.c_uint(y0), C.c_uint(w), C.c_uint(local_rows),
+                                                              C.c_uint(band_rows), C.c_uint(band_stride)))
+        if ok:
+            self.tile = self.backend.tile = (x0, y0, w, local_rows)
         return ok
 
     def set_sun(self, az, alt, direct=True):

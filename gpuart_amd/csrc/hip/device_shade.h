@@ -8,10 +8,16 @@ namespace gd {
 /// Everything a render kernel needs besides the scene (passed by value as a kernel argument).
 struct Frame {
     uint32_t W, H;             ///< full frame
-    uint32_t x0, y0, tw, th;   ///< this context's tile
+    uint32_t x0, y0, tw, th;   ///< this context's tile: tw x th local pixels starting at (x0, y0)
+    uint32_t band_rows, band_stride;  ///< local row ly is frame row y0 + (ly / band_rows) * band_stride + ly % band_rows
+                                      ///< (band_rows = band_stride = th: a plain rectangle; otherwise row bands interleaved
+                                      ///<  with other contexts for load balance)
     float cam_pos[3], bottom_left[3], delta_horz[3], delta_vert[3];
     float uv_coef[12];         ///< llvmpipe plane equations of the quad's UV (A.u A.v B.u B.v)
 };
+
+/// Frame row of local row `ly` of the tile.
+GD_FN uint32_t frame_y(const Frame &f, uint32_t ly) { return f.y0 + (ly / f.band_rows) * f.band_stride + ly % f.band_rows; }
 
 // ---- reference shaders/vertex.glsl:29-37 as rasterised by llvmpipe (DESIGN.md "UV") -----------
 GD_FN void pixel_uv(const Frame &f, uint32_t x, uint32_t y, float &u, float &v) {

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, float4 
         uint32_t q = SLOT_INVALID;
         if (valid) {
             F3 rs0, rd0, rs, rd;
-            camera_ray(f, f.x0 + lx, f.y0 + ly, rs0, rd0);
+            camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
             if (no_segments) {  // the GLSL loop body never runs: i == 0 and no user-sphere hit
                 path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, 0, false, false, f3(0, 0, 0)));
             } else {
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
             if (s.broke) {
                 uint32_t lx, ly; F3 rs0, rd0;
                 slot_pixel(f, slot, lx, ly);
-                camera_ray(f, f.x0 + lx, f.y0 + ly, rs0, rd0);
+                camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                 path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, seg, s.ush, s.specular, pathColor));
             } else {
                 go_on = s.next == PATH_CONTINUES;
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_para
         uint32_t lx, ly;
         if (!slot_pixel(f, slot, lx, ly)) continue;
         F3 rs, rd;
-        camera_ray(f, f.x0 + lx, f.y0 + ly, rs, rd);
+        camera_ray(f, f.x0 + lx, frame_y(f, ly), rs, rd);
         F3 c = direct_lighting_pixel<REFWORK>(sc, P, rs, rd, st, &wc);
         out[(size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 1.0f);
     }
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_par
         uint32_t lx, ly;
         if (!slot_pixel(f, slot, lx, ly)) continue;
         F3 rs, rd;
-        camera_ray(f, f.x0 + lx, f.y0 + ly, rs, rd);
+        camera_ray(f, f.x0 + lx, frame_y(f, ly), rs, rd);
         F3 c = path_tracing_pixel<REFWORK>(sc, P, seed, npaths, rs, rd, st, &wc, segments);
         size_t idx = (size_t)ly * f.tw + lx;
         float4 prev = accum[idx];
@@ -433,7 +433,7 @@ __global__ void k_test_cam_rays(Frame f, float4 *rstart, float4 *rdir) {
     if (i >= f.tw * f.th) return;
     uint32_t lx = i % f.tw, ly = i / f.tw;
     F3 s, d;
-    camera_ray(f, f.x0 + lx, f.y0 + ly, s, d);
+    camera_ray(f, f.x0 + lx, frame_y(f, ly), s, d);
     rstart[i] = make_float4(s.x, s.y, s.z, 0);
     rdir[i] = make_float4(d.x, d.y, d.z, 0);
 }
@@ -843,6 +843,7 @@ int gpuart_hip_resize(gpuart_hip_ctx *c, uint32_t width, uint32_t height) {
     HIP_TRY(hipSetDevice(c->device));
     c->frame.W = width; c->frame.H = height;
     c->frame.x0 = 0; c->frame.y0 = 0; c->frame.tw = width; c->frame.th = height;
+    c->frame.band_rows = height; c->frame.band_stride = height;
     update_uv(c);
     return realloc_tile(c);
 }
@@ -853,6 +854,21 @@ int gpuart_hip_set_tile(gpuart_hip_ctx *c, uint32_t x0, uint32_t y0, uint32_t tw
         return fail(GPUART_HIP_ERR_ARG, "tile outside the frame");
     HIP_TRY(hipSetDevice(c->device));
     c->frame.x0 = x0; c->frame.y0 = y0; c->frame.tw = tw; c->frame.th = th;
+    c->frame.band_rows = th; c->frame.band_stride = th;
+    return realloc_tile(c);
+}
+
+int gpuart_hip_set_tile_interleaved(gpuart_hip_ctx *c, uint32_t x0, uint32_t y0, uint32_t tw, uint32_t th_local,
+                                    uint32_t band_rows, uint32_t band_stride) {
+    if (!c || !c->frame.W) return fail(GPUART_HIP_ERR_ARG, "set_tile before resize");
+    if (tw == 0 || th_local == 0 || band_rows == 0 || band_stride < band_rows || (uint64_t)x0 + tw > c->frame.W)
+        return fail(GPUART_HIP_ERR_ARG, "bad interleaved tile");
+    // the last local row must still lie inside the frame
+    const uint64_t last = (uint64_t)y0 + (uint64_t)((th_local - 1) / band_rows) * band_stride + (th_local - 1) % band_rows;
+    if (last >= c->frame.H) return fail(GPUART_HIP_ERR_ARG, "interleaved tile outside the frame");
+    HIP_TRY(hipSetDevice(c->device));
+    c->frame.x0 = x0; c->frame.y0 = y0; c->frame.tw = tw; c->frame.th = th_local;
+    c->frame.band_rows = band_rows; c->frame.band_stride = band_stride;
     return realloc_tile(c);
 }
 

@@ -129,6 +129,10 @@ int gpuart_renderer_update_viewport(gpuart_renderer *r, unsigned w, unsigned h) 
 int gpuart_renderer_set_tile(gpuart_renderer *r, unsigned x0, unsigned y0, unsigned w, unsigned h) {
     return r->impl.SetTile(x0, y0, w, h) ? 1 : 0;
 }
+int gpuart_renderer_set_interleaved_tile(gpuart_renderer *r, unsigned x0, unsigned y0, unsigned w, unsigned localRows,
+                                         unsigned bandRows, unsigned bandStride) {
+    return r->impl.SetInterleavedTile(x0, y0, w, localRows, bandRows, bandStride) ? 1 : 0;
+}
 void gpuart_renderer_set_sun(gpuart_renderer *r, float azimuth, float altitude, int directLighting) {
     r->impl.SetSunAzimuth(azimuth);
     r->impl.SetSunAltitude(altitude);

@@ -47,6 +47,8 @@ int gpuart_renderer_set_camera(gpuart_renderer *r, const float pos[3], const flo
                                float screenDist);
 int gpuart_renderer_update_viewport(gpuart_renderer *r, unsigned width, unsigned height);
 int gpuart_renderer_set_tile(gpuart_renderer *r, unsigned x0, unsigned y0, unsigned w, unsigned h);
+int gpuart_renderer_set_interleaved_tile(gpuart_renderer *r, unsigned x0, unsigned y0, unsigned w, unsigned localRows,
+                                         unsigned bandRows, unsigned bandStride);
 void gpuart_renderer_set_sun(gpuart_renderer *r, float azimuth, float altitude, int directLighting);
 void gpuart_renderer_set_user_sphere(gpuart_renderer *r, const float pos[3], float radius, float emittance, int specular,
                                      int fuzzy);

@@ -95,6 +95,16 @@ bool Renderer::SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h) {
     return true;
 }
 
+bool Renderer::SetInterleavedTile(unsigned x0, unsigned y0, unsigned w, unsigned localRows, unsigned bandRows,
+                                  unsigned bandStride) {
+    if (!Backend) return false;
+    if (!Check(gpuart_hip_set_tile_interleaved(Backend, x0, y0, w, localRows, bandRows, bandStride), "setting the tile"))
+        return false;
+    Tile.x = x0; Tile.y = y0; Tile.w = w; Tile.h = localRows;
+    ResetPathTracing();
+    return true;
+}
+
 bool Renderer::SetCamera(const Camera &cam) {
     CurrentCamera = cam;
     if (!Backend) return false;

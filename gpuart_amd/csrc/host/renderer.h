@@ -90,6 +90,8 @@ public:
     void SetSeed(uint32_t seed) { RndGen.seed(seed); ResetPathTracing(); }
     /// Restricts this renderer to a tile of the frame (screen-space sharding across GPUs).
     bool SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h);
+    /// Row bands interleaved with other renderers (rank r of N: y0 = bandRows*r, bandStride = bandRows*N).
+    bool SetInterleavedTile(unsigned x0, unsigned y0, unsigned w, unsigned localRows, unsigned bandRows, unsigned bandStride);
     unsigned GetNumPathsRendered() const { return PathTracing.numPathsRendered; }
     /// Progressive-render checkpoint: accumulator + pass counters + RNG state of this tile.
     /// After LoadCheckpoint the following passes are bit-identical to those of the uninterrupted run. The

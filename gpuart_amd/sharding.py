@@ -45,3 +45,33 @@ def gather_bands(dist, band, bands, rank, full=None, root=0):
         return full
     dist.isend(band.contiguous(), dst=root).wait()
     return None
+
+
+def interleaved_rows(rank, world, height, band=8):
+    """Frame rows owned by `rank` when row bands of `band` rows are dealt round-robin to the ranks
+    (band k goes to rank k % world). Returns (y0, local_rows, band_rows, band_stride, rows) where `rows` is the
+    array of frame rows in local order — the arguments of gpuart_hip_set_tile_interleaved plus the scatter map."""
+    nbands = (height + band - 1) // band
+    mine = np.arange(rank, nbands, world)
+    rows = np.concatenate([np.arange(b * band, min(height, (b + 1) * band)) for b in mine]) if len(mine) else np.zeros(0, int)
+    return rank * band, int(len(rows)), band, band * world, rows
+
+
+def gather_interleaved(dist, local, rank, world, height, full=None, root=0, band=8):
+    """Gathers interleaved row bands (local: (local_rows, W, C) tensor) into `full` (height, W, C) on root."""
+    import torch
+    if rank == root:
+        for src in range(world):
+            _, n, _, _, rows = interleaved_rows(src, world, height, band)
+            if n == 0:
+                continue
+            if src == root:
+                buf = local
+            else:
+                buf = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+                dist.recv(buf, src=src)
+            full[torch.as_tensor(rows, device=full.device)] = buf
+        return full
+    if local.shape[0]:
+        dist.send(local.contiguous(), dst=root)
+    return None

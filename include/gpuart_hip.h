@@ -69,6 +69,11 @@ int gpuart_hip_destroy(gpuart_hip_ctx *ctx);
  * the tile this context owns (default: the whole frame). Clears the accumulator. */
 int gpuart_hip_resize(gpuart_hip_ctx *ctx, uint32_t width, uint32_t height);
 int gpuart_hip_set_tile(gpuart_hip_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t tw, uint32_t th);
+/* Row-interleaved tile for load-balanced multi-GPU sharding: the context owns th_local rows, local row ly being
+ * frame row y0 + (ly / band_rows) * band_stride + ly % band_rows (e.g. rank r of N: y0 = 8r, band_rows = 8,
+ * band_stride = 8N). Buffers and read-backs are tw x th_local, local row order. */
+int gpuart_hip_set_tile_interleaved(gpuart_hip_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t tw, uint32_t th_local,
+                                    uint32_t band_rows, uint32_t band_stride);
 
 /* Replaces the GL_TEXTURE_BUFFER upload of Renderer::SetPrimitives (reference
  * src/renderer.cpp:472-475). `quads` is the reference's canonical compiled tree

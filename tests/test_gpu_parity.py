@@ -469,6 +469,27 @@ def test_full_size_tile_split_equals_whole_frame(B, be, O, dragon_1080p):
     assert_bits(whole[y0:y0 + th, x0:x0 + tw, :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "1080p window vs oracle")
 
 
+def test_full_size_interleaved_tiles_equal_whole_frame(B, be, O, dragon_1080p):
+    """The 8-way interleaved sharding bench.py uses at N=8: every rank's rows are bit-identical to the whole frame's."""
+    from gpuart_amd import sharding
+    W, H, c, tree, P = dragon_1080p
+    seeds = O.randseeds(2)
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    be.pt_reset()
+    for k in range(2):
+        be.pt_pass(to_params(B, P), seeds[k], 1)
+    whole = be.read(1)
+    for rank in (0, 3, 7):
+        y0, n, band, stride, rows = sharding.interleaved_rows(rank, 8, H)
+        be.set_tile_interleaved(0, y0, W, n, band, stride)
+        be.pt_reset()
+        for k in range(2):
+            be.pt_pass(to_params(B, P), seeds[k], 1)
+        part = be.read(1)
+        assert bit_mismatch(part.reshape(-1, 4), whole[rows].reshape(-1, 4)) == 0, rank
+    be.set_tile(0, 0, W, H)
+
+
 def test_full_size_accumulation_is_additive(B, be, O, dragon_1080p):
     """accum after passes (s0, s1) == single-pass(s0) + single-pass(s1) in float32 (path_tracing.glsl:255)."""
     W, H, c, tree, P = dragon_1080p

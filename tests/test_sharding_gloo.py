@@ -25,6 +25,19 @@ def test_balanced_bands_properties():
                 assert max(loads) < 1.35 * (sum(loads) / world)
 
 
+def test_interleaved_rows_partition_the_frame():
+    for world in (1, 2, 3, 8):
+        for height in (8, 60, 1080, 2160, 4321):
+            seen = np.zeros(height, int)
+            for rank in range(world):
+                y0, n, band, stride, rows = sharding.interleaved_rows(rank, world, height)
+                assert n == len(rows) and band == 8 and stride == 8 * world and y0 == 8 * rank
+                ly = np.arange(n)
+                np.testing.assert_array_equal(rows, y0 + (ly // band) * stride + ly % band)  # the device's frame_y()
+                seen[rows] += 1
+            assert (seen == 1).all()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -48,8 +61,15 @@ def _worker(rank, world, port, H, W, q):
     dist.barrier()
     out = sharding.gather_bands(dist, band, bands, rank, full)
     dist.barrier()
+    # the interleaved form used by bench.py: 8-row bands dealt round-robin
+    _, n, _, _, rows = sharding.interleaved_rows(rank, world, H)
+    local = torch.from_numpy(_pixel_value(H, W)[rows].copy())
+    full2 = torch.zeros((H, W, 4)) if rank == 0 else None
+    out2 = sharding.gather_interleaved(dist, local, rank, world, H, full2)
+    dist.barrier()
     if rank == 0:
-        q.put((bands, bool((out.numpy() == _pixel_value(H, W)).all())))
+        ok = bool((out.numpy() == _pixel_value(H, W)).all()) and bool((out2.numpy() == _pixel_value(H, W)).all())
+        q.put((bands, ok))
     dist.destroy_process_group()
 
 
