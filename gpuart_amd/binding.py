@@ -3,6 +3,8 @@
 import ctypes as C
 import os
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")  # see libgpuart_hip's request_hw_queues(); before any HIP initialisation
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -91,18 +91,27 @@ GD_FN void queue_push(uint32_t *queue, uint32_t *counter, bool pred, uint32_t va
     if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1))] = value;
 }
 
-/// Adds a finished path's colour to its pixel (path_tracing.glsl:252,255): color += pathColor for every
-/// path of the pass, then accum = PrevRadiance + color.
-GD_FN void path_commit(const Frame &f, const PathBuffers &b, float4 *accum, uint32_t slot, int j, int npaths, F3 value) {
+/// Adds a finished path's colour to its pixel's colour of this pass (path_tracing.glsl:252: color += pathColor for
+/// every path of the pass). The last path stores the pass colour in `passcolor` (tile row-major); k_accumulate then
+/// performs path_tracing.glsl:255, accum = PrevRadiance + color, in pass order.
+GD_FN void path_commit(const Frame &f, const PathBuffers &b, float4 *passcolor, uint32_t slot, int j, int npaths, F3 value) {
     F3 c = (j == 0) ? f3(0.0f + value.x, 0.0f + value.y, 0.0f + value.z) : xyz(b.color[slot]) + value;
     if (j == npaths - 1) {
         uint32_t lx, ly;
         slot_pixel(f, slot, lx, ly);
-        size_t idx = (size_t)ly * f.tw + lx;
-        float4 prev = accum[idx];
-        accum[idx] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
+        passcolor[(size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 0);
     } else
         b.color[slot] = make_float4(c.x, c.y, c.z, 0);
+}
+
+/// path_tracing.glsl:255 for one finished pass: accum = PrevRadiance + color. Launched in pass order on the
+/// context's primary stream, so float additions happen in the reference's order whatever the overlap of passes.
+__global__ void k_accumulate(float4 *__restrict__ accum, const float4 *__restrict__ passcolor, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float4 prev = accum[i], c = passcolor[i];
+        accum[i] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
+    }
 }
 
 // ---- wavefront stage 0: first ray of path j of every pixel (path_tracing.glsl:141-175) ---------------
@@ -447,6 +456,12 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Passes in flight live on 2 streams each (+ the primary stream). ROCm maps HIP streams onto GPU_MAX_HW_QUEUES
+// hardware queues (default 4) and kernels of streams that share a queue serialise, which would undo the overlap
+// the pass lanes exist for; ask for more queues unless the user has chosen a value. Must happen before the HIP
+// runtime initialises, hence a load-time constructor (bench.py also sets it before importing torch).
+__attribute__((constructor)) void request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
@@ -481,24 +496,37 @@ struct TimedLaunch {
 
 }  // namespace
 
+/// Everything one path-tracing pass needs while it is in flight. Several passes are in flight at once (each on its
+/// own pair of streams); their kernels fill each other's tails, which matters most for small tiles (multi-GPU).
+struct PassLane {
+    hipStream_t main = nullptr;    ///< gen / closest-hit queries / shading
+    hipStream_t shadow = nullptr;  ///< Sun-shadow queries of segment s, beside the closest-hit queries of s+1
+    PathBuffers pb{};              ///< wavefront path state (tile-sized)
+    void *pathmem = nullptr;
+    float4 *passcolor = nullptr;   ///< this pass's colour per pixel, added to the accumulator by k_accumulate
+    uint4 *spill_main = nullptr, *spill_shadow = nullptr;  ///< traversal-stack overflow, one per stream
+    uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
+    std::vector<hipEvent_t> ev_shaded, ev_shadowed;  ///< per segment: shading done (main) / shadow pass done (shadow)
+    hipEvent_t ev_done = nullptr;  ///< the pass has finished (main stream)
+    hipEvent_t ev_free = nullptr;  ///< its colour has been accumulated (primary stream): the lane may be reused
+    bool used = false;
+};
+
 struct gpuart_hip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  ///< primary stream: accumulation (in pass order), direct lighting, copies, test hooks
     Frame frame{};
     bool have_camera = false, have_scene = false;
     float4 *d_nodes = nullptr, *d_prims = nullptr;
-    uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow
-    uint4 *d_spill2 = nullptr;     ///< the same for kernels on the second stream
-    hipStream_t stream2 = nullptr; ///< Sun-shadow queries of segment s run here, beside the closest-hit queries of s+1
-    std::vector<hipEvent_t> ev_shaded, ev_shadowed;  ///< per segment: shading done (main stream) / shadow pass done (stream2)
-    int overlap = 1;
+    uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow for kernels on the primary stream
+    std::vector<PassLane> lanes;
+    uint32_t next_lane = 0;
+    int overlap = 1;               ///< run shadow queries beside the next closest-hit queries
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
     TraceTuning tune{64, 16, 1};
-    PathBuffers pb{};              ///< wavefront path state (tile-sized)
-    void *d_pathmem = nullptr;
-    uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
+    uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
     uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
@@ -518,7 +546,19 @@ struct gpuart_hip_ctx {
 
 namespace {
 
+/// Waits for everything this context has enqueued, on all of its streams.
+int drain(gpuart_hip_ctx *c) {
+    for (auto &l : c->lanes) {
+        if (l.main) HIP_TRY(hipStreamSynchronize(l.main));
+        if (l.shadow) HIP_TRY(hipStreamSynchronize(l.shadow));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int realloc_tile(gpuart_hip_ctx *c) {
+    int r = drain(c);
+    if (r) return r;
     if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; }
     if (c->d_accum) { (void)hipFree(c->d_accum); c->d_accum = nullptr; }
     c->tile_pixels = (size_t)c->frame.tw * c->frame.th;
@@ -527,49 +567,62 @@ int realloc_tile(gpuart_hip_ctx *c) {
     HIP_TRY(hipMalloc(&c->d_accum, c->tile_pixels * sizeof(float4)));
     HIP_TRY(hipMemsetAsync(c->d_direct, 0, c->tile_pixels * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
-    // wavefront path state: one slot per pixel of the 8x8-tile-padded tile
-    if (c->d_pathmem) { (void)hipFree(c->d_pathmem); c->d_pathmem = nullptr; }
+    // wavefront path state: one slot per pixel of the 8x8-tile-padded tile, per pass in flight
     const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
     const size_t n = tiles * 64;
     if (n > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
-    const size_t bytes = n * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t));
-    HIP_TRY(hipMalloc(&c->d_pathmem, bytes));
-    char *m = (char *)c->d_pathmem;
-    PathBuffers &b = c->pb;
-    uint32_t *keep_counters = b.counters;
-    b.ray_o = (float4 *)m; m += n * sizeof(float4);
-    b.ray_d = (float4 *)m; m += n * sizeof(float4);
-    b.cw = (float4 *)m; m += n * sizeof(float4);
-    b.pc = (float4 *)m; m += n * sizeof(float4);
-    b.sun = (float4 *)m; m += n * sizeof(float4);
-    b.color = (float4 *)m; m += n * sizeof(float4);
-    b.hit = (uint2 *)m; m += n * sizeof(uint2);
-    b.queue[0] = (uint32_t *)m; m += n * sizeof(uint32_t);
-    b.queue[1] = (uint32_t *)m; m += n * sizeof(uint32_t);
-    b.shadow_queue = (uint32_t *)m;
-    b.counters = keep_counters;
-    b.n_slots = (uint32_t)n;
+    c->n_slots = (uint32_t)n;
+    const size_t bytes = n * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + c->tile_pixels * sizeof(float4);
+    for (auto &l : c->lanes) {
+        if (l.pathmem) { (void)hipFree(l.pathmem); l.pathmem = nullptr; }
+        HIP_TRY(hipMalloc(&l.pathmem, bytes));
+        char *m = (char *)l.pathmem;
+        PathBuffers &b = l.pb;
+        b.ray_o = (float4 *)m; m += n * sizeof(float4);
+        b.ray_d = (float4 *)m; m += n * sizeof(float4);
+        b.cw = (float4 *)m; m += n * sizeof(float4);
+        b.pc = (float4 *)m; m += n * sizeof(float4);
+        b.sun = (float4 *)m; m += n * sizeof(float4);
+        b.color = (float4 *)m; m += n * sizeof(float4);
+        l.passcolor = (float4 *)m; m += c->tile_pixels * sizeof(float4);
+        b.hit = (uint2 *)m; m += n * sizeof(uint2);
+        b.queue[0] = (uint32_t *)m; m += n * sizeof(uint32_t);
+        b.queue[1] = (uint32_t *)m; m += n * sizeof(uint32_t);
+        b.shadow_queue = (uint32_t *)m;
+        b.n_slots = (uint32_t)n;
+        l.used = false;
+    }
     return 0;
 }
 
-int ensure_segment_counters(gpuart_hip_ctx *c, uint32_t nseg) {
-    if (c->pb.counters && c->counter_segments >= nseg) return 0;
-    if (c->pb.counters) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->pb.counters); c->pb.counters = nullptr; }
-    HIP_TRY(hipMalloc(&c->pb.counters, 4 * ((size_t)nseg + 1) * sizeof(uint32_t)));
-    c->counter_segments = nseg;
+int ensure_segment_counters(gpuart_hip_ctx *c, PassLane &l, uint32_t nseg) {
+    if (l.pb.counters && l.counter_segments >= nseg) return 0;
+    if (l.pb.counters) { int r = drain(c); if (r) return r; (void)hipFree(l.pb.counters); l.pb.counters = nullptr; }
+    HIP_TRY(hipMalloc(&l.pb.counters, 4 * ((size_t)nseg + 1) * sizeof(uint32_t)));
+    l.counter_segments = nseg;
+    while (l.ev_shaded.size() < nseg) {
+        hipEvent_t e1, e2;
+        HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        l.ev_shaded.push_back(e1); l.ev_shadowed.push_back(e2);
+    }
     return 0;
 }
 
 int ensure_spill(gpuart_hip_ctx *c) {
     const uint32_t levels = c->max_depth > GD_RING ? c->max_depth - GD_RING : 0;
     if (c->d_spill && c->spill_levels >= levels) return 0;
-    if (c->d_spill) {
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(c->d_spill); (void)hipFree(c->d_spill2);
-        c->d_spill = c->d_spill2 = nullptr;
+    int r = drain(c);
+    if (r) return r;
+    const size_t bytes = ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4);
+    if (c->d_spill) { (void)hipFree(c->d_spill); c->d_spill = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_spill, bytes));
+    for (auto &l : c->lanes) {
+        if (l.spill_main) { (void)hipFree(l.spill_main); l.spill_main = nullptr; }
+        if (l.spill_shadow) { (void)hipFree(l.spill_shadow); l.spill_shadow = nullptr; }
+        HIP_TRY(hipMalloc(&l.spill_main, bytes));
+        HIP_TRY(hipMalloc(&l.spill_shadow, bytes));
     }
-    HIP_TRY(hipMalloc(&c->d_spill, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4)));
-    HIP_TRY(hipMalloc(&c->d_spill2, ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4)));
     c->spill_levels = levels;
     return 0;
 }
@@ -786,6 +839,8 @@ extern "C" {
 
 const char *gpuart_hip_last_error(void) { return g_last_error.c_str(); }
 
+int gpuart_hip_destroy(gpuart_hip_ctx *c);
+
 int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     if (!out) return fail(GPUART_HIP_ERR_ARG, "out == NULL");
     *out = nullptr;
@@ -807,13 +862,22 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
         return (uint32_t)std::min<long>(hi, std::max<long>(lo, x));
     };
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 12, 1, 32);  // persistent grids of one-wave workgroups
+    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 6, 1, 32);  // persistent grids of one-wave workgroups
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 1, 1, 64);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->overlap = (int)env_u32("GPUART_HIP_OVERLAP", 1, 0, 1);
+    c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
+    for (auto &l : c->lanes) {
+        if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&l.shadow, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l.ev_free, hipEventDisableTiming) != hipSuccess) {
+            gpuart_hip_destroy(c);
+            return fail(GPUART_HIP_ERR_DEVICE, "stream / event creation failed");
+        }
+    }
     if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return fail(GPUART_HIP_ERR_DEVICE, "counter allocation failed");
@@ -825,15 +889,22 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
 int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)drain(c);
     for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    for (auto e : c->ev_shaded) (void)hipEventDestroy(e);
-    for (auto e : c->ev_shadowed) (void)hipEventDestroy(e);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_spill, c->d_spill2, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_pathmem, c->pb.counters};
+    for (auto &l : c->lanes) {
+        for (auto e : l.ev_shaded) (void)hipEventDestroy(e);
+        for (auto e : l.ev_shadowed) (void)hipEventDestroy(e);
+        if (l.ev_done) (void)hipEventDestroy(l.ev_done);
+        if (l.ev_free) (void)hipEventDestroy(l.ev_free);
+        void *lp[] = {l.pathmem, l.spill_main, l.spill_shadow, l.pb.counters};
+        for (void *p : lp) if (p) (void)hipFree(p);
+        if (l.main) (void)hipStreamDestroy(l.main);
+        if (l.shadow) (void)hipStreamDestroy(l.shadow);
+    }
+    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -881,6 +952,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     if (!cv.node(0, 0, root)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
     Converter::sanitize(root);
     int r;
+    if ((r = drain(c))) return r;
     if ((r = upload_vec(c, c->d_nodes, cv.recs))) return r;
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
@@ -915,12 +987,12 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
     int r = check_ready(c, p);
     if (r) return r;
     HIP_TRY(hipSetDevice(c->device));
-    dim3 grid(std::min<uint32_t>(c->grid_waves, c->pb.n_slots / BLOCK));
+    dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
     Scene sc = scene_of(c);
     TimedLaunch t;
     if ((r = begin_timed(c, t, 0))) return r;
-    if (c->mode == 1) k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->pb.n_slots, c->d_direct, c->d_spill, c->d_counters);
-    else k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->pb.n_slots, c->d_direct, c->d_spill, c->d_counters);
+    if (c->mode == 1) k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
+    else k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
     HIP_TRY(hipGetLastError());
     return end_timed(c, t);
 }
@@ -928,6 +1000,9 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
 int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
     if (!c || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
     HIP_TRY(hipSetDevice(c->device));
+    // passes still in flight belong to the accumulation that is being discarded: let them finish first
+    int r = drain(c);
+    if (r) return r;
     HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
     return 0;
 }
@@ -966,66 +1041,73 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
     HIP_TRY(hipSetDevice(c->device));
     Scene sc = scene_of(c);
     const float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
-    const PathBuffers &b = c->pb;
     TimedLaunch t;
-    if ((r = begin_timed(c, t, 0))) return r;
-    if (c->mode == 2) {  // megakernel: the whole path in one thread (ablation / cross-check)
-        dim3 grid(std::min<uint32_t>(c->grid_waves, b.n_slots / BLOCK));
-        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, b.n_slots, c->d_accum, c->d_spill, c->d_counters);
+    if (c->mode == 2) {  // megakernel: the whole path in one thread, on the primary stream (ablation / cross-check)
+        if ((r = begin_timed(c, t, 0))) return r;
+        dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
+        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->n_slots, c->d_accum, c->d_spill, c->d_counters);
         HIP_TRY(hipGetLastError());
         return end_timed(c, t);
     }
+    // ---- wavefront pipeline on the next pass lane ----
+    PassLane &l = c->lanes[c->next_lane];
+    c->next_lane = (c->next_lane + 1) % (uint32_t)c->lanes.size();
     const uint32_t nseg = segment_bound(c, p);
-    if ((r = ensure_segment_counters(c, nseg))) return r;
+    if ((r = ensure_segment_counters(c, l, nseg))) return r;
+    const PathBuffers &b = l.pb;
     const bool refwork = c->mode == 1;
+    const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots / BLOCK));
-    while (c->ev_shaded.size() < nseg) {
-        hipEvent_t e1, e2;
-        HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-        c->ev_shaded.push_back(e1); c->ev_shadowed.push_back(e2);
-    }
+    if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous pass has been accumulated
+    if ((r = begin_timed(c, t, 0, l.main))) return r;
     for (int j = 0; j < npaths; j++) {
         int shadow_pending = -1;
-        HIP_TRY(hipMemsetAsync(c->pb.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), c->stream));
-        k_gen<<<sgrid, BLOCK, 0, c->stream>>>(c->frame, *p, seed, j, npaths, b, c->d_accum);
+        HIP_TRY(hipMemsetAsync(b.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
+        k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seed, j, npaths, b, l.passcolor);
         for (uint32_t seg = 0; seg < nseg; seg++) {
             TimedLaunch tt;
-            const bool detail = c->timing_level >= 2;
-            if (detail && (r = begin_timed(c, tt, 1))) return r;
-            if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
-            else k_trace<false, false, false><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, c->d_spill, c->d_counters, c->tune);
-            if (detail && (r = end_timed(c, tt))) return r;
+            if (detail && (r = begin_timed(c, tt, 1, l.main))) return r;
+            if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+            else k_trace<false, false, false><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+            if (detail && (r = end_timed(c, tt, l.main))) return r;
             if (shadow_pending >= 0) {  // the previous segment's shadow pass updates pathColor, which shading reads
-                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shadowed[shadow_pending], 0));
+                HIP_TRY(hipStreamWaitEvent(l.main, l.ev_shadowed[shadow_pending], 0));
                 shadow_pending = -1;
             }
-            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
-            else k_shade<false><<<sgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, c->d_accum, c->d_counters);
+            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
+            else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
             if (p->sunEnabled == 1) {
-                // The Sun-shadow queries of this segment run on the second stream, beside the closest-hit queries
-                // of the next segment (independent data); the next shading kernel waits for them.
-                hipStream_t ss = c->overlap ? c->stream2 : c->stream;
-                uint4 *sspill = c->overlap ? c->d_spill2 : c->d_spill;
+                // The Sun-shadow queries of this segment run on the lane's second stream, beside the closest-hit
+                // queries of the next segment (independent data); the next shading kernel waits for them.
+                hipStream_t ss = c->overlap ? l.shadow : l.main;
+                uint4 *sspill = c->overlap ? l.spill_shadow : l.spill_main;
                 if (c->overlap) {
-                    HIP_TRY(hipEventRecord(c->ev_shaded[seg], c->stream));
-                    HIP_TRY(hipStreamWaitEvent(ss, c->ev_shaded[seg], 0));
+                    HIP_TRY(hipEventRecord(l.ev_shaded[seg], l.main));
+                    HIP_TRY(hipStreamWaitEvent(ss, l.ev_shaded[seg], 0));
                 }
                 if (detail && (r = begin_timed(c, tt, 1, ss))) return r;
-                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, sspill, c->d_counters, c->tune);
-                else k_trace<true, true, false><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, c->d_accum, sspill, c->d_counters, c->tune);
+                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
+                else k_trace<true, true, false><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
                 if (detail && (r = end_timed(c, tt, ss))) return r;
                 if (c->overlap) {
-                    HIP_TRY(hipEventRecord(c->ev_shadowed[seg], ss));
+                    HIP_TRY(hipEventRecord(l.ev_shadowed[seg], ss));
                     shadow_pending = (int)seg;
                 }
             }
         }
-        if (shadow_pending >= 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shadowed[shadow_pending], 0));
+        if (shadow_pending >= 0) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_shadowed[shadow_pending], 0));
         HIP_TRY(hipGetLastError());
     }
-    return end_timed(c, t);
+    if ((r = end_timed(c, t, l.main))) return r;
+    // accumulate in pass order on the primary stream, then release the lane
+    HIP_TRY(hipEventRecord(l.ev_done, l.main));
+    HIP_TRY(hipStreamWaitEvent(c->stream, l.ev_done, 0));
+    k_accumulate<<<dim3((unsigned)((c->tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->tile_pixels);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(l.ev_free, c->stream));
+    l.used = true;
+    return 0;
 }
 
 int gpuart_hip_export(gpuart_hip_ctx *c, int which, void *rgba_device, float divide_by) {
@@ -1067,12 +1149,14 @@ int gpuart_hip_write(gpuart_hip_ctx *c, int which, const float *rgba_host) {
 int gpuart_hip_finish(gpuart_hip_ctx *c) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return drain(c);
 }
 
 int gpuart_hip_set_mode(gpuart_hip_ctx *c, int mode) {
     if (!c || mode < 0 || mode > 2) return fail(GPUART_HIP_ERR_ARG, "bad mode");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = drain(c);  // modes use different streams; keep their passes ordered
+    if (r) return r;
     c->mode = mode;
     return 0;
 }
@@ -1087,6 +1171,8 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[8];
+    int rr = drain(c);
+    if (rr) return rr;
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (out) {

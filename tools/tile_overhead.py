@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-pass time of rank 0's share of the 1080p frame for N = 1, 2, 4, 8 interleaved ranks, on one GPU:
+shows the fixed per-pass cost that limits strong scaling (ideal: t(N) = t(1)/N)."""
+import os, sys, time
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from gpuart_amd import binding as B, sharding, synth_scenes as S
+W, H, K = 1920, 1080, 20
+cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
+r = B.Renderer(W, H, cam)
+r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+r.set_primitives(B.make_prims(S.scene_d()))
+r.set_max_path_segments(8)
+r.backend.set_timing(0)
+t1 = None
+for n in (1, 2, 4, 8):
+    worst = 0
+    for rank in sorted(set([0, n - 1])):
+        if n > 1:
+            y0, rows, band, stride, _ = sharding.interleaved_rows(rank, n, H)
+            assert r.set_interleaved_tile(0, y0, W, rows, band, stride)
+        r.restart_path_tracing(1, 3); [r.path_tracing_pass() for _ in range(3)]; r.finish()
+        r.set_seed(5489); r.restart_path_tracing(1, K)
+        t0 = time.perf_counter()
+        for _ in range(K): r.path_tracing_pass()
+        r.finish()
+        worst = max(worst, (time.perf_counter() - t0) / K * 1e3)
+    t1 = t1 or worst
+    print("N=%d  %.3f ms/pass (slowest of first/last rank)  speed-up %.2fx  efficiency %.0f%%" % (n, worst, t1 / worst, 100 * t1 / worst / n))
