@@ -44,7 +44,15 @@ struct PathBuffers {
     uint32_t *queue[2];      ///< slots that trace segment s (ping-pong)
     uint32_t *shadow_queue;  ///< slots with a pending Sun shadow query
     uint32_t *counters;      ///< per segment s: [4s] rays, [4s+1] fetch cursor, [4s+2] shadow rays, [4s+3] fetch cursor
-    uint32_t n_slots;
+    uint32_t n_slots;        ///< path slots per pass (pixels of the tile, 8x8-tile padded)
+    uint32_t batch;          ///< passes processed together: slot s belongs to pass s / n_slots, pixel slot s % n_slots
+    uint32_t tile_pixels;    ///< stride between the passes' colour planes in `passcolor`
+};
+
+#define MAX_BATCH 8
+/// RandSeed of every pass of a batch (passes are batched so that small tiles still fill the GPU).
+struct SeedBatch {
+    float4 seed[MAX_BATCH];
 };
 #define SLOT_INVALID 0xffffffffu
 
@@ -98,29 +106,35 @@ GD_FN void path_commit(const Frame &f, const PathBuffers &b, float4 *passcolor, 
     F3 c = (j == 0) ? f3(0.0f + value.x, 0.0f + value.y, 0.0f + value.z) : xyz(b.color[slot]) + value;
     if (j == npaths - 1) {
         uint32_t lx, ly;
-        slot_pixel(f, slot, lx, ly);
-        passcolor[(size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 0);
+        slot_pixel(f, slot % b.n_slots, lx, ly);
+        passcolor[(size_t)(slot / b.n_slots) * b.tile_pixels + (size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 0);
     } else
         b.color[slot] = make_float4(c.x, c.y, c.z, 0);
 }
 
 /// path_tracing.glsl:255 for one finished pass: accum = PrevRadiance + color. Launched in pass order on the
 /// context's primary stream, so float additions happen in the reference's order whatever the overlap of passes.
-__global__ void k_accumulate(float4 *__restrict__ accum, const float4 *__restrict__ passcolor, size_t n) {
+__global__ void k_accumulate(float4 *__restrict__ accum, const float4 *__restrict__ passcolor, size_t n, uint32_t batch) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        float4 prev = accum[i], c = passcolor[i];
-        accum[i] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
+        float4 a = accum[i];
+        for (uint32_t k = 0; k < batch; k++) {  // the passes of a batch, oldest first
+            float4 c = passcolor[(size_t)k * n + i];
+            a = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w);
+        }
+        accum[i] = a;
     }
 }
 
 // ---- wavefront stage 0: first ray of path j of every pixel (path_tracing.glsl:141-175) ---------------
-__global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, float4 seed, int j, int npaths, PathBuffers b,
+__global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBatch seeds, int j, int npaths, PathBuffers b,
                                                float4 *accum) {
     const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < b.n_slots; slot += gridDim.x * BLOCK) {
+    const uint32_t total = b.n_slots * b.batch;
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < total; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;
-        bool valid = slot_pixel(f, slot, lx, ly);
+        bool valid = slot_pixel(f, slot % b.n_slots, lx, ly);
+        const float4 seed = seeds.seed[slot / b.n_slots];
         uint32_t q = SLOT_INVALID;
         if (valid) {
             F3 rs0, rd0, rs, rd;
@@ -138,7 +152,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, float4 
         }
         b.queue[0][slot] = q;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.counters[0] = no_segments ? 0u : b.n_slots;
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.counters[0] = no_segments ? 0u : total;
 }
 
 // ---- wavefront stage 1/3: BVH queries for a whole queue, persistent waves with lane refill -----------
@@ -241,7 +255,7 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
 
 // ---- wavefront stage 2: shade segment `seg` of every path in queue[seg&1] (path_tracing.glsl:182-233) ---
 template <bool REFWORK>
-__global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_params P, float4 seed, PathBuffers b, int seg,
+__global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int seg,
                                                  int j, int npaths, float4 *accum, unsigned long long *gcounters) {
     // Survivors are appended to the next queues through a per-wave staging list in LDS that is flushed with
     // ONE atomic per SHADE_ROUNDS*64 processed paths: a single atomic word sustains only ~90 appends/us on
@@ -265,10 +279,11 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
             F3 cw = xyz(b.cw[slot]), pathColor = xyz(b.pc[slot]);
             F3 rstart = r.o, rdir = r.d;
             segments++;
+            const float4 seed = seeds.seed[slot / b.n_slots];
             ShadeResult s = path_shade(sc, P, seed, seg, r, __uint_as_float(h.x), h.y, rstart, rdir, cw, pathColor);
             if (s.broke) {
                 uint32_t lx, ly; F3 rs0, rd0;
-                slot_pixel(f, slot, lx, ly);
+                slot_pixel(f, slot % b.n_slots, lx, ly);
                 camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                 path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, seg, s.ush, s.specular, pathColor));
             } else {
@@ -527,6 +542,12 @@ struct gpuart_hip_ctx {
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
     TraceTuning tune{64, 16, 1};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
+    uint32_t max_batch = 1;        ///< passes batched into one run of the pipeline (small tiles: up to MAX_BATCH)
+    uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
+    // passes requested through gpuart_hip_pt_pass but not launched yet (same params, one seed each)
+    std::vector<float4> pend_seeds;
+    gpuart_params pend_params{};
+    int pend_npaths = 0;
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
     uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
@@ -556,9 +577,14 @@ int drain(gpuart_hip_ctx *c) {
     return 0;
 }
 
+}  // namespace
+extern "C" int gpuart_hip_flush(gpuart_hip_ctx *c);
+namespace {
+
 int realloc_tile(gpuart_hip_ctx *c) {
-    int r = drain(c);
+    int r = gpuart_hip_flush(c);
     if (r) return r;
+    if ((r = drain(c))) return r;
     if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; }
     if (c->d_accum) { (void)hipFree(c->d_accum); c->d_accum = nullptr; }
     c->tile_pixels = (size_t)c->frame.tw * c->frame.th;
@@ -572,24 +598,31 @@ int realloc_tile(gpuart_hip_ctx *c) {
     const size_t n = tiles * 64;
     if (n > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
     c->n_slots = (uint32_t)n;
-    const size_t bytes = n * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + c->tile_pixels * sizeof(float4);
+    // small tiles run several passes per pipeline run so that every launch still has ~2M paths to work on
+    const size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, ((size_t)1 << 21) / n));
+    if (n * B > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
+    c->max_batch = (uint32_t)B;
+    const size_t bytes = n * B * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + B * c->tile_pixels * sizeof(float4);
     for (auto &l : c->lanes) {
         if (l.pathmem) { (void)hipFree(l.pathmem); l.pathmem = nullptr; }
         HIP_TRY(hipMalloc(&l.pathmem, bytes));
         char *m = (char *)l.pathmem;
         PathBuffers &b = l.pb;
-        b.ray_o = (float4 *)m; m += n * sizeof(float4);
-        b.ray_d = (float4 *)m; m += n * sizeof(float4);
-        b.cw = (float4 *)m; m += n * sizeof(float4);
-        b.pc = (float4 *)m; m += n * sizeof(float4);
-        b.sun = (float4 *)m; m += n * sizeof(float4);
-        b.color = (float4 *)m; m += n * sizeof(float4);
-        l.passcolor = (float4 *)m; m += c->tile_pixels * sizeof(float4);
-        b.hit = (uint2 *)m; m += n * sizeof(uint2);
-        b.queue[0] = (uint32_t *)m; m += n * sizeof(uint32_t);
-        b.queue[1] = (uint32_t *)m; m += n * sizeof(uint32_t);
+        const size_t nb = n * B;
+        b.ray_o = (float4 *)m; m += nb * sizeof(float4);
+        b.ray_d = (float4 *)m; m += nb * sizeof(float4);
+        b.cw = (float4 *)m; m += nb * sizeof(float4);
+        b.pc = (float4 *)m; m += nb * sizeof(float4);
+        b.sun = (float4 *)m; m += nb * sizeof(float4);
+        b.color = (float4 *)m; m += nb * sizeof(float4);
+        l.passcolor = (float4 *)m; m += B * c->tile_pixels * sizeof(float4);
+        b.hit = (uint2 *)m; m += nb * sizeof(uint2);
+        b.queue[0] = (uint32_t *)m; m += nb * sizeof(uint32_t);
+        b.queue[1] = (uint32_t *)m; m += nb * sizeof(uint32_t);
         b.shadow_queue = (uint32_t *)m;
         b.n_slots = (uint32_t)n;
+        b.batch = 1;
+        b.tile_pixels = (uint32_t)c->tile_pixels;
         l.used = false;
     }
     return 0;
@@ -869,6 +902,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->overlap = (int)env_u32("GPUART_HIP_OVERLAP", 1, 0, 1);
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
+    c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&l.shadow, hipStreamNonBlocking) != hipSuccess ||
@@ -889,6 +923,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
 int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
+    c->pend_seeds.clear();
     (void)drain(c);
     for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -952,6 +987,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     if (!cv.node(0, 0, root)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
     Converter::sanitize(root);
     int r;
+    if ((r = gpuart_hip_flush(c))) return r;
     if ((r = drain(c))) return r;
     if ((r = upload_vec(c, c->d_nodes, cv.recs))) return r;
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
@@ -969,6 +1005,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
 
 int gpuart_hip_set_camera(gpuart_hip_ctx *c, const float pos[3], const float bl[3], const float dh[3], const float dv[3]) {
     if (!c || !pos || !bl || !dh || !dv) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }  // batched passes were requested with the old camera
     memcpy(c->frame.cam_pos, pos, 12); memcpy(c->frame.bottom_left, bl, 12);
     memcpy(c->frame.delta_horz, dh, 12); memcpy(c->frame.delta_vert, dv, 12);
     c->have_camera = true;
@@ -986,6 +1023,7 @@ static int check_ready(gpuart_hip_ctx *c, const gpuart_params *p) {
 int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
     int r = check_ready(c, p);
     if (r) return r;
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     HIP_TRY(hipSetDevice(c->device));
     dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
     Scene sc = scene_of(c);
@@ -1000,6 +1038,7 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
 int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
     if (!c || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     // passes still in flight belong to the accumulation that is being discarded: let them finish first
     int r = drain(c);
     if (r) return r;
@@ -1033,38 +1072,34 @@ static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
     return std::max<uint32_t>(bound, 1);
 }
 
-int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float randSeed[4], int npaths) {
-    int r = check_ready(c, p);
-    if (r) return r;
-    if (!randSeed || npaths < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
-    if (npaths == 0) return 0;
+/// Launches the collected passes as one run of the wavefront pipeline on the next pass lane.
+int gpuart_hip_flush(gpuart_hip_ctx *c) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    if (c->pend_seeds.empty()) return 0;
     HIP_TRY(hipSetDevice(c->device));
+    int r;
+    const gpuart_params *p = &c->pend_params;
+    const int npaths = c->pend_npaths;
     Scene sc = scene_of(c);
-    const float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
     TimedLaunch t;
-    if (c->mode == 2) {  // megakernel: the whole path in one thread, on the primary stream (ablation / cross-check)
-        if ((r = begin_timed(c, t, 0))) return r;
-        dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
-        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->n_slots, c->d_accum, c->d_spill, c->d_counters);
-        HIP_TRY(hipGetLastError());
-        return end_timed(c, t);
-    }
-    // ---- wavefront pipeline on the next pass lane ----
     PassLane &l = c->lanes[c->next_lane];
     c->next_lane = (c->next_lane + 1) % (uint32_t)c->lanes.size();
     const uint32_t nseg = segment_bound(c, p);
+    l.pb.batch = (uint32_t)c->pend_seeds.size();
+    SeedBatch seeds{};
+    for (size_t k = 0; k < c->pend_seeds.size(); k++) seeds.seed[k] = c->pend_seeds[k];
     if ((r = ensure_segment_counters(c, l, nseg))) return r;
     const PathBuffers &b = l.pb;
     const bool refwork = c->mode == 1;
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
-    const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots / BLOCK));
+    const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots * b.batch / BLOCK));
     if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous pass has been accumulated
     if ((r = begin_timed(c, t, 0, l.main))) return r;
     for (int j = 0; j < npaths; j++) {
         int shadow_pending = -1;
         HIP_TRY(hipMemsetAsync(b.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
-        k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seed, j, npaths, b, l.passcolor);
+        k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seeds, j, npaths, b, l.passcolor);
         for (uint32_t seg = 0; seg < nseg; seg++) {
             TimedLaunch tt;
             if (detail && (r = begin_timed(c, tt, 1, l.main))) return r;
@@ -1075,8 +1110,8 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
                 HIP_TRY(hipStreamWaitEvent(l.main, l.ev_shadowed[shadow_pending], 0));
                 shadow_pending = -1;
             }
-            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
-            else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seed, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
+            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
+            else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
             if (p->sunEnabled == 1) {
                 // The Sun-shadow queries of this segment run on the lane's second stream, beside the closest-hit
                 // queries of the next segment (independent data); the next shading kernel waits for them.
@@ -1103,16 +1138,47 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
     // accumulate in pass order on the primary stream, then release the lane
     HIP_TRY(hipEventRecord(l.ev_done, l.main));
     HIP_TRY(hipStreamWaitEvent(c->stream, l.ev_done, 0));
-    k_accumulate<<<dim3((unsigned)((c->tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->tile_pixels);
+    k_accumulate<<<dim3((unsigned)((c->tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->tile_pixels, b.batch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(l.ev_free, c->stream));
     l.used = true;
+    c->pend_seeds.clear();
+    return 0;
+}
+
+
+int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float randSeed[4], int npaths) {
+    int r = check_ready(c, p);
+    if (r) return r;
+    if (!randSeed || npaths < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (npaths == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
+    if (c->mode == 2) {  // megakernel: the whole path in one thread, on the primary stream (ablation / cross-check)
+        if ((r = gpuart_hip_flush(c))) return r;
+        Scene sc = scene_of(c);
+        TimedLaunch t;
+        if ((r = begin_timed(c, t, 0))) return r;
+        dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
+        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->n_slots, c->d_accum, c->d_spill, c->d_counters);
+        HIP_TRY(hipGetLastError());
+        return end_timed(c, t);
+    }
+    // Passes are collected and launched max_batch at a time (1 for large tiles). A pass with different parameters
+    // starts a new batch; anything that observes or changes state flushes first.
+    if (!c->pend_seeds.empty() && (memcmp(&c->pend_params, p, sizeof *p) != 0 || c->pend_npaths != npaths))
+        if ((r = gpuart_hip_flush(c))) return r;
+    c->pend_params = *p;
+    c->pend_npaths = npaths;
+    c->pend_seeds.push_back(seed);
+    if (c->pend_seeds.size() >= c->max_batch) return gpuart_hip_flush(c);
     return 0;
 }
 
 int gpuart_hip_export(gpuart_hip_ctx *c, int which, void *rgba_device, float divide_by) {
     if (!c || !rgba_device || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     const float4 *src = which == 0 ? c->d_direct : c->d_accum;
     if (!(divide_by > 0)) divide_by = 1.0f;
     size_t n = c->tile_pixels;
@@ -1124,6 +1190,7 @@ int gpuart_hip_export(gpuart_hip_ctx *c, int which, void *rgba_device, float div
 int gpuart_hip_read(gpuart_hip_ctx *c, int which, float *rgba_host, float divide_by) {
     if (!c || !rgba_host || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     size_t bytes = c->tile_pixels * sizeof(float4);
     const float4 *src = which == 0 ? c->d_direct : c->d_accum;
     if (divide_by > 0 && divide_by != 1.0f) {
@@ -1141,6 +1208,7 @@ int gpuart_hip_read(gpuart_hip_ctx *c, int which, float *rgba_host, float divide
 int gpuart_hip_write(gpuart_hip_ctx *c, int which, const float *rgba_host) {
     if (!c || !rgba_host || which != 1 || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     HIP_TRY(hipMemcpyAsync(c->d_accum, rgba_host, c->tile_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -1149,12 +1217,14 @@ int gpuart_hip_write(gpuart_hip_ctx *c, int which, const float *rgba_host) {
 int gpuart_hip_finish(gpuart_hip_ctx *c) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     return drain(c);
 }
 
 int gpuart_hip_set_mode(gpuart_hip_ctx *c, int mode) {
     if (!c || mode < 0 || mode > 2) return fail(GPUART_HIP_ERR_ARG, "bad mode");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     int r = drain(c);  // modes use different streams; keep their passes ordered
     if (r) return r;
     c->mode = mode;
@@ -1163,6 +1233,7 @@ int gpuart_hip_set_mode(gpuart_hip_ctx *c, int mode) {
 
 int gpuart_hip_set_timing(gpuart_hip_ctx *c, int level) {
     if (!c || level < 0 || level > 2) return fail(GPUART_HIP_ERR_ARG, "bad timing level");
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     c->timing_level = level;
     return 0;
 }
@@ -1170,6 +1241,7 @@ int gpuart_hip_set_timing(gpuart_hip_ctx *c, int level) {
 int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     unsigned long long h[8];
     int rr = drain(c);
     if (rr) return rr;
@@ -1187,6 +1259,7 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
 int gpuart_hip_kernel_time(gpuart_hip_ctx *c, int cls, double *total_ms, uint64_t *launches, int reset) {
     if (!c || cls < 0 || cls > 1) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     int r = fold_timings(c);
     if (r) return r;
     if (total_ms) *total_ms = c->timed_ms[cls];

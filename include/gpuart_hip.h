@@ -112,6 +112,12 @@ int gpuart_hip_write(gpuart_hip_ctx *ctx, int which, const float *rgba_host);
  * hands it to RCCL). Asynchronous on the context's stream; call gpuart_hip_finish before use. */
 int gpuart_hip_export(gpuart_hip_ctx *ctx, int which, void *rgba_device, float divide_by);
 
+/* glFlush() equivalent. gpuart_hip_pt_pass may only *collect* a pass: on small tiles several passes with identical
+ * parameters are launched together as one batch (so that every kernel launch still has millions of paths), and up to
+ * 8 batches are in flight at once on separate HIP streams; results are accumulated strictly in pass order. Everything
+ * that observes or changes state (read, export, finish, reset, set_camera, ...) flushes by itself. */
+int gpuart_hip_flush(gpuart_hip_ctx *ctx);
+
 /* glFinish() equivalent (reference src/main.cpp:564,584). */
 int gpuart_hip_finish(gpuart_hip_ctx *ctx);
 
