@@ -161,10 +161,17 @@ def main():
         assert same, "gathered frame differs from the single-rank frame"
 
     mrays = rays / elapsed / 1e6
-    # dominant kernel = k_trace (all BVH queries: closest-hit + Sun shadow launches); its launches of the K timed
-    # passes process my_alg_bytes algorithmic bytes in kernel_ms milliseconds (HIP events around every launch)
+    # Dominant kernel = k_trace (all BVH queries: the closest-hit and Sun-shadow launches of the wavefront pipeline).
+    # HIP events around every launch (recorded on the launching stream, inside the timed region) give its average launch
+    # duration. Several passes are in flight at once, so launches OVERLAP: `concurrency` = sum of launch durations / wall
+    # time. `achieved` is the aggregate rate of the kernel (all algorithmic bytes its launches processed / wall time of
+    # the timed region, = bytes per launch / (average launch duration / concurrency)); `achieved_per_launch` is what one
+    # launch sees while it shares the GPU with the others (bytes per launch / average launch duration).
     avg_kernel_ms = kernel_ms / max(1, launches)
-    achieved_gbs = (my_alg_bytes / max(1, launches)) / (avg_kernel_ms * 1e-3) / 1e9
+    concurrency = kernel_ms / (elapsed * 1e3)
+    bytes_per_launch = my_alg_bytes / max(1, launches)
+    achieved_per_launch = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+    achieved_gbs = my_alg_bytes / elapsed / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -217,9 +224,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": "k_trace (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
-                     "kernel_avg_ms": round(avg_kernel_ms, 5), "launches": launches,
-                     "kernel_ms_per_pass": round(kernel_ms / K, 4), "pass_ms_device": round(pass_ms / max(1, passes), 4),
-                     "algorithmic_bytes_per_launch": my_alg_bytes / max(1, launches),
+                     "kernel_avg_ms": round(avg_kernel_ms, 5), "launches": launches, "concurrency": round(concurrency, 3),
+                     "achieved_per_launch": round(achieved_per_launch, 2),
+                     "kernel_ms_per_pass": round(kernel_ms / K, 4),
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
                      "algorithmic_bytes_per_pass": my_alg_bytes / K,
                      "algorithmic_bytes_per_ray": round(alg_bytes / rays, 1) if rays else None},
         "cpu_baseline": cpu_baseline,
