@@ -490,6 +490,42 @@ def test_full_size_interleaved_tiles_equal_whole_frame(B, be, O, dragon_1080p):
     be.set_tile(0, 0, W, H)
 
 
+def test_4k_and_8k_configs(B, O):
+    """cfg4 (3840x2160, whole frame on one GPU) and cfg5 (7680x4320, one of 8 interleaved shares): a few progressive
+    passes through the Renderer API; windows of the result against the oracle, whole-frame sanity."""
+    from gpuart_amd import sharding
+    cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
+    prims = B.make_prims(S.scene_d())
+    tree, _ = O.build_bvh(S.scene_d())
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    seeds = O.randseeds(3)
+    for (W, H, share) in [(3840, 2160, None), (7680, 4320, (5, 8))]:
+        r = B.Renderer(W, H, cam)
+        r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+        r.set_primitives(prims)
+        r.set_max_path_segments(8)
+        rows = np.arange(H)
+        if share:
+            y0, n, band, stride, rows = sharding.interleaved_rows(share[0], share[1], H)
+            assert r.set_interleaved_tile(0, y0, W, n, band, stride)
+        r.restart_path_tracing(1, 3)
+        assert [r.path_tracing_pass() for _ in range(3)] == [1, 2, 3]
+        acc = r.read_radiance(False)
+        r.close()
+        assert acc.shape == (len(rows), W, 4) and np.isfinite(acc[..., :3]).all() and acc[..., :3].min() >= 0
+        # an oracle window in the middle of the mesh: 64 columns x the first 16 local rows at/after frame row H/2
+        c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+        P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 8, 0.01)
+        l0 = int(np.searchsorted(rows, H // 2))
+        x0 = W // 2 - 32
+        for k in range(l0, l0 + 16, 8):      # 8-row groups are contiguous frame rows in both layouts
+            gy = int(rows[k])
+            exp = np.zeros((8, 64, 4), np.float32)
+            for sd in seeds:
+                O.pt_pass(tree, c, W, H, P, sd, 1, exp, tile=(x0, gy, 64, 8), nthreads=4)
+            assert_bits(acc[k:k + 8, x0:x0 + 64, :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "%dx%d window" % (W, H))
+
+
 def test_full_size_accumulation_is_additive(B, be, O, dragon_1080p):
     """accum after passes (s0, s1) == single-pass(s0) + single-pass(s1) in float32 (path_tracing.glsl:255)."""
     W, H, c, tree, P = dragon_1080p
