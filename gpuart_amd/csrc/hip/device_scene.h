@@ -24,8 +24,6 @@ namespace gd {
 enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #define GD_VISIBILITY_OFFSET 1.0e-4f
 #define GD_NO_PRIM 0xffffffffu
-#define GD_USER_SPHERE 0xfffffffeu
-#define GD_META_LEAF 0x80000000u
 
 #define GD_REF_LEAF 0x80000000u
 #define GD_REF_TRIS 0x40000000u  ///< with GD_REF_LEAF: the leaf holds only triangles, one or two of them
@@ -36,8 +34,6 @@ struct Scene {
     const float4 *__restrict__ prims;
     float root_min[3], root_max[3];
     uint32_t root_ref;    ///< record index, or GD_REF_LEAF | first primitive
-    uint32_t num_nodes;
-    uint32_t max_depth;
 };
 
 struct Ray {

@@ -532,7 +532,7 @@ struct gpuart_hip_ctx {
     hipStream_t stream = nullptr;  ///< primary stream: accumulation (in pass order), direct lighting, copies, test hooks
     Frame frame{};
     bool have_camera = false, have_scene = false;
-    float4 *d_nodes = nullptr, *d_prims = nullptr;
+    float4 *d_recs = nullptr, *d_prims = nullptr;
     uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow for kernels on the primary stream
     std::vector<PassLane> lanes;
     uint32_t next_lane = 0;
@@ -671,12 +671,10 @@ void update_uv(gpuart_hip_ctx *c) {
 
 Scene scene_of(const gpuart_hip_ctx *c) {
     Scene s;
-    s.recs = c->d_nodes;
+    s.recs = c->d_recs;
     memcpy(s.root_min, c->root_min, 12); memcpy(s.root_max, c->root_max, 12);
     s.root_ref = c->root_ref;
     s.prims = c->d_prims;
-    s.num_nodes = (uint32_t)c->n_nodes;
-    s.max_depth = c->max_depth;
     return s;
 }
 
@@ -937,7 +935,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
         if (l.main) (void)hipStreamDestroy(l.main);
         if (l.shadow) (void)hipStreamDestroy(l.shadow);
     }
-    void *ptrs[] = {c->d_nodes, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
+    void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -989,7 +987,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     int r;
     if ((r = gpuart_hip_flush(c))) return r;
     if ((r = drain(c))) return r;
-    if ((r = upload_vec(c, c->d_nodes, cv.recs))) return r;
+    if ((r = upload_vec(c, c->d_recs, cv.recs))) return r;
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
     c->root_ref = root.ref;

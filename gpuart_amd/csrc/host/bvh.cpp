@@ -8,8 +8,11 @@
 
 #include <algorithm>
 #include <cassert>
+#include <future>
+#include <cstdlib>
 #include <cstring>
 #include <ostream>
+#include <system_error>
 
 namespace gpuart {
 
@@ -17,13 +20,11 @@ namespace {
 inline float as_float(uint32_t u) { float f; std::memcpy(&f, &u, sizeof f); return f; }
 inline uint32_t as_uint(float f) { uint32_t u; std::memcpy(&u, &f, sizeof u); return u; }
 
-inline float box_lo(const Primitive *p, int axis) { return axis == 0 ? p->GetXmin() : axis == 1 ? p->GetYmin() : p->GetZmin(); }
-inline float box_hi(const Primitive *p, int axis) { return axis == 0 ? p->GetXmax() : axis == 1 ? p->GetYmax() : p->GetZmax(); }
-
 template <int AXIS>
 struct CentreLess {
-    bool operator()(const Primitive *a, const Primitive *b) const {
-        return (box_lo(a, AXIS) + box_hi(a, AXIS)) * 0.5 < (box_lo(b, AXIS) + box_hi(b, AXIS)) * 0.5;
+    template <typename Item>
+    bool operator()(const Item &a, const Item &b) const {
+        return (a.lo[AXIS] + a.hi[AXIS]) * 0.5 < (b.lo[AXIS] + b.hi[AXIS]) * 0.5;
     }
 };
 }  // namespace
@@ -31,37 +32,50 @@ struct CentreLess {
 BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &primitives, unsigned maxNumLevels,
                                                    unsigned minPrimitivesPerNode) {
     NumPrimitives = primitives.size();
-    Nodes.reserve(primitives.size() + 1);
-    Subdivide(primitives, 0, primitives.size(), 0, maxNumLevels, minPrimitivesPerNode, 0, false);
+    // the build sorts (box, pointer) items instead of chasing the pointers in every comparison; std::sort's sequence of
+    // moves depends only on the comparison results, so the order is the one sorting the pointers would give
+    std::vector<Item> items(primitives.size());
+    for (size_t i = 0; i < primitives.size(); i++) {
+        const Primitive *p = primitives[i];
+        items[i] = Item{{p->GetXmin(), p->GetYmin(), p->GetZmin()}, {p->GetXmax(), p->GetYmax(), p->GetZmax()}, primitives[i]};
+    }
+    Subtree root;
+    root.nodes.reserve(primitives.size() + 1);
+    // fork the top levels when the scene is large enough to pay for the threads (2^4 = 16 tasks at most)
+    int budget = primitives.size() >= 32768 ? 4 : 0;
+    if (const char *e = std::getenv("GPUART_BVH_FORK_LEVELS")) budget = std::atoi(e);
+    SubdivideParallel(root, items, 0, items.size(), 0, maxNumLevels, minPrimitivesPerNode, budget);
+    for (size_t i = 0; i < items.size(); i++) primitives[i] = items[i].p;  // the reference leaves the caller's list sorted too
+    Nodes = std::move(root.nodes);
+    LeafData = std::move(root.leafData);
+    Depth = root.depth;
 }
 
-void BoundingVolumesHierarchy::Subdivide(std::vector<Primitive *> &prims, size_t from, size_t to, unsigned level,
-                                         unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent,
-                                         bool isLower) {
-    const uint32_t self = (uint32_t)Nodes.size();
-    Nodes.emplace_back();
-    if (level > Depth) Depth = level;
+bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to,
+                                           unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
+                                           size_t &split) {
+    if (level > out.depth) out.depth = level;
     {
-        Node &n = Nodes.back();
-        n.parent = parent; n.isLower = isLower; n.higher = 0; n.count = 0; n.dataBegin = n.dataEnd = 0;
+        Node &n = out.nodes[self];
+        n.higher = 0; n.count = 0; n.dataBegin = n.dataEnd = 0;
         for (int k = 0; k < 3; k++) { n.lo[k] = 99.0e+29f; n.hi[k] = -99.0e+29f; }
         for (size_t i = from; i < to; i++)
             for (int k = 0; k < 3; k++) {
-                float lo = box_lo(prims[i], k), hi = box_hi(prims[i], k);
+                const float lo = prims[i].lo[k], hi = prims[i].hi[k];
                 if (lo < n.lo[k]) n.lo[k] = lo;
                 if (hi > n.hi[k]) n.hi[k] = hi;
             }
     }
-    const float xr = Nodes[self].hi[0] - Nodes[self].lo[0], yr = Nodes[self].hi[1] - Nodes[self].lo[1],
-                zr = Nodes[self].hi[2] - Nodes[self].lo[2];
+    const float xr = out.nodes[self].hi[0] - out.nodes[self].lo[0], yr = out.nodes[self].hi[1] - out.nodes[self].lo[1],
+                zr = out.nodes[self].hi[2] - out.nodes[self].lo[2];
 
     if (to - from <= minPrimitivesPerNode || level == maxNumLevels - 1) {
-        Node &n = Nodes[self];
+        Node &n = out.nodes[self];
         n.count = (uint32_t)(to - from);
-        n.dataBegin = LeafData.size();
-        for (size_t i = from; i < to; i++) prims[i]->StoreIntoBVH(LeafData);
-        n.dataEnd = LeafData.size();
-        return;
+        n.dataBegin = out.leafData.size();
+        for (size_t i = from; i < to; i++) prims[i].p->StoreIntoBVH(out.leafData);
+        n.dataEnd = out.leafData.size();
+        return true;
     }
 
     int axis;
@@ -74,17 +88,76 @@ void BoundingVolumesHierarchy::Subdivide(std::vector<Primitive *> &prims, size_t
     else if (axis == 1) std::sort(first, last, CentreLess<1>());
     else std::sort(first, last, CentreLess<2>());
 
-    const double middle = Nodes[self].lo[axis] + 0.5 * range;
-    size_t split = from;
-    while (split < to && 0.5 * (box_lo(prims[split], axis) + box_hi(prims[split], axis)) <= middle) split++;
+    const double middle = out.nodes[self].lo[axis] + 0.5 * range;
+    split = from;
+    while (split < to && 0.5 * (prims[split].lo[axis] + prims[split].hi[axis]) <= middle) split++;
     if (to - from > 2) {  // a dominating box must not capture everything on one side
         if (split == from) split++;
         else if (split == to) split--;
     }
+    return false;
+}
 
-    Subdivide(prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, self, true);
-    Nodes[self].higher = (uint32_t)Nodes.size();
-    Subdivide(prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, self, false);
+void BoundingVolumesHierarchy::Subdivide(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+                                         unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent,
+                                         bool isLower) {
+    const uint32_t self = (uint32_t)out.nodes.size();
+    out.nodes.emplace_back();
+    out.nodes[self].parent = parent;
+    out.nodes[self].isLower = isLower;
+    size_t split;
+    if (PrepareNode(out, self, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split)) return;
+    Subdivide(out, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, self, true);
+    out.nodes[self].higher = (uint32_t)out.nodes.size();
+    Subdivide(out, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, self, false);
+}
+
+void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item> &prims, size_t from, size_t to,
+                                                 unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
+                                                 int budget) {
+    if (budget <= 0 || to - from < 8192) {
+        Subdivide(out, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, 0, false);
+        return;
+    }
+    // this node (index 0 of `out`), then the two halves as independent subtrees spliced behind it in pre-order
+    out.nodes.emplace_back();
+    out.nodes[0].parent = 0;
+    out.nodes[0].isLower = false;
+    size_t split;
+    if (PrepareNode(out, 0, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split)) return;
+    Subtree lo, hi;
+    // a lopsided split (one dominating primitive) is not worth a thread and does not use up the fork budget
+    const bool fork = std::min(split - from, to - split) >= 4096;
+    const int below = fork ? budget - 1 : budget;
+    auto buildLo = [&] { SubdivideParallel(lo, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, below); };
+    std::future<void> task;
+    if (fork) {
+        try {
+            task = std::async(std::launch::async, buildLo);
+        } catch (const std::system_error &) {  // no thread to be had: build this half here
+        }
+    }
+    SubdivideParallel(hi, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, below);
+    if (task.valid()) task.get();
+    else buildLo();
+    auto splice = [&out](Subtree &sub, bool isLower) {
+        const uint32_t base = (uint32_t)out.nodes.size();
+        const size_t dataBase = out.leafData.size();
+        for (size_t i = 0; i < sub.nodes.size(); i++) {
+            Node n = sub.nodes[i];
+            if (i == 0) { n.parent = 0; n.isLower = isLower; }
+            else n.parent += base;
+            if (n.higher) n.higher += base;
+            n.dataBegin += dataBase;
+            n.dataEnd += dataBase;
+            out.nodes.push_back(n);
+        }
+        out.leafData.insert(out.leafData.end(), sub.leafData.begin(), sub.leafData.end());
+        if (sub.depth > out.depth) out.depth = sub.depth;
+    };
+    splice(lo, true);
+    out.nodes[0].higher = (uint32_t)out.nodes.size();
+    splice(hi, false);
 }
 
 void BoundingVolumesHierarchy::Compile(Primitive::Data &out) const {

@@ -53,13 +53,34 @@ private:
         uint32_t count;         ///< primitives in a leaf (0 = interior node)
         size_t dataBegin, dataEnd;  ///< leaf payload range in LeafData (floats)
     };
+    /// A primitive during the build: its box and itself.
+    struct Item {
+        float lo[3], hi[3];
+        Primitive *p;
+    };
+    /// A subtree under construction: nodes in pre-order with indices relative to the subtree, its own leaf payloads.
+    struct Subtree {
+        std::vector<Node> nodes;
+        std::vector<float> leafData;
+        unsigned depth = 0;  ///< deepest level reached (absolute)
+    };
     std::vector<Node> Nodes;          ///< pre-order
     std::vector<float> LeafData;      ///< serialised primitives of all leaves, in leaf order
     size_t NumPrimitives = 0;
     unsigned Depth = 0;
 
-    void Subdivide(std::vector<Primitive *> &prims, size_t from, size_t to, unsigned level, unsigned maxNumLevels,
-                   unsigned minPrimitivesPerNode, uint32_t parent, bool isLower);
+    /// Sequential build of [from, to) appended to `out` (reference src/bvh.cpp:35-152).
+    static void Subdivide(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+                          unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent, bool isLower);
+    /// The same tree, built with the two halves of large nodes in parallel tasks; `budget` = how many
+    /// more levels may fork. Byte-identical to the sequential build: the per-node sort and split are unchanged, the
+    /// halves work on disjoint ranges of `prims`.
+    static void SubdivideParallel(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+                                  unsigned maxNumLevels, unsigned minPrimitivesPerNode, int budget);
+    /// Fills node `self` of `out` with the box of [from, to); returns true if it became a leaf, else sorts the range
+    /// along the split axis and returns the split position.
+    static bool PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+                            unsigned maxNumLevels, unsigned minPrimitivesPerNode, size_t &split);
 };
 
 }  // namespace gpuart

@@ -2,6 +2,9 @@
 #include "capi.h"
 
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,9 +43,18 @@ void free_list(std::vector<Primitive *> &v) {
 
 int compile_list(std::vector<Primitive *> &list, unsigned maxLevels, unsigned minPrims, float **quads, size_t *nquads,
                  unsigned *depth) {
+    const bool timing = std::getenv("GPUART_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     BoundingVolumesHierarchy tree(list, maxLevels, minPrims);
+    const auto t1 = std::chrono::steady_clock::now();
     Primitive::Data data;
     tree.Compile(data);
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gpuart] BVH of %zu primitives: build %.1f ms, compile %.1f ms\n", list.size(),
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
     *quads = (float *)malloc(data.size() * sizeof(float) + 16);
     if (!*quads) return -1;
     memcpy(*quads, data.data(), data.size() * sizeof(float));
