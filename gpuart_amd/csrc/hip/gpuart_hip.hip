@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
     uint32_t chunk_next = min(blockIdx.x * tune.chunk, n), chunk_end = min((blockIdx.x + 1) * tune.chunk, n);  // wave-uniform
     bool exhausted = false;                                                                                   // wave-uniform
     uint32_t slot = SLOT_INVALID;
-    Ray r; r.o = f3(0, 0, 0); r.d = f3(1, 0, 0);
+    F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0);  // the ray (two F3 locals: a long-lived Ray aggregate ends up in scratch)
     F3 rdiv = f3(1, 1, 1);
     Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
 
@@ -207,10 +207,10 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
                 uint32_t s = queue[chunk_next + rank];
                 if (s != SLOT_INVALID) {
                     slot = s;
-                    r.o = xyz(b.ray_o[s]);
-                    r.d = SHADOW ? sun : xyz(b.ray_d[s]);
-                    rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
-                    trav_init(sc, r, rdiv, t, st, &wc, COUNT);
+                    ro = xyz(b.ray_o[s]);
+                    rd = SHADOW ? sun : xyz(b.ray_d[s]);
+                    rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                    trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
                 }
             }
             chunk_next += take;
@@ -223,12 +223,12 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
         }
         // ---- traverse until enough lanes have finished
         for (;;) {
-            if (slot != SLOT_INVALID && t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, r, rdiv, t, st, COUNT ? &wc : nullptr);
+            if (slot != SLOT_INVALID && t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
             if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
                 if (slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS))
-                    trav_step_leaf<ANY, COUNT>(sc, r, t, st, COUNT ? &wc : nullptr);
+                    trav_step_leaf<ANY, COUNT>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                 descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
                 at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             }
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
             } else {
                 float4 term = b.sun[slot];
                 F3 pathColor = xyz(b.pc[slot]);
-                if (sun_visible(P, r.o, sun, t.hit_prim)) pathColor = pathColor + xyz(term);
+                if (sun_visible(P, ro, sun, t.hit_prim)) pathColor = pathColor + xyz(term);
                 if (__float_as_uint(term.w) & 1u) path_commit(f, b, accum, slot, j, npaths, pathColor);
                 else b.pc[slot] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
             }
@@ -540,10 +540,13 @@ struct gpuart_hip_ctx {
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
-    TraceTuning tune{64, 16, 1};
+    TraceTuning tune{64, 16, 8};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
     uint32_t max_batch = 1;        ///< passes batched into one run of the pipeline (small tiles: up to MAX_BATCH)
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
+    size_t batch_paths = (size_t)16 << 20;  ///< passes are batched while one pipeline run stays within this many paths
+    uint32_t lanes_in_use = 1;     ///< pass lanes cycled through (all of them unless their path state would exceed lane_budget)
+    size_t lane_budget = (size_t)8 << 30;  ///< bytes of wavefront path state over all lanes
     // passes requested through gpuart_hip_pt_pass but not launched yet (same params, one seed each)
     std::vector<float4> pend_seeds;
     gpuart_params pend_params{};
@@ -598,13 +601,21 @@ int realloc_tile(gpuart_hip_ctx *c) {
     const size_t n = tiles * 64;
     if (n > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
     c->n_slots = (uint32_t)n;
-    // small tiles run several passes per pipeline run so that every launch still has ~2M paths to work on
-    const size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, ((size_t)1 << 21) / n));
+    // Several passes run through the pipeline together (slot = pass x pixel) while that stays within `batch_paths`
+    // paths: a persistent k_trace wave then takes many rays per lane, and the drain at the end of every launch — waves
+    // finishing their last, long rays with few lanes busy — shrinks relative to the useful work (SQ_INSTS_VALU per
+    // ray falls by a quarter from 2M to 16M paths per launch at 1080p).
+    const size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, c->batch_paths / n));
     if (n * B > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
     c->max_batch = (uint32_t)B;
     const size_t bytes = n * B * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + B * c->tile_pixels * sizeof(float4);
-    for (auto &l : c->lanes) {
+    c->lanes_in_use = (uint32_t)std::min<size_t>(c->lanes.size(), std::max<size_t>(2, c->lane_budget / bytes));
+    c->next_lane = 0;
+    for (size_t li = 0; li < c->lanes.size(); li++) {
+        PassLane &l = c->lanes[li];
         if (l.pathmem) { (void)hipFree(l.pathmem); l.pathmem = nullptr; }
+        l.used = false;
+        if (li >= c->lanes_in_use) continue;
         HIP_TRY(hipMalloc(&l.pathmem, bytes));
         char *m = (char *)l.pathmem;
         PathBuffers &b = l.pb;
@@ -623,7 +634,6 @@ int realloc_tile(gpuart_hip_ctx *c) {
         b.n_slots = (uint32_t)n;
         b.batch = 1;
         b.tile_pixels = (uint32_t)c->tile_pixels;
-        l.used = false;
     }
     return 0;
 }
@@ -896,11 +906,13 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 6, 1, 32);  // persistent grids of one-wave workgroups
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
-    c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 1, 1, 64);
+    c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 8, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->overlap = (int)env_u32("GPUART_HIP_OVERLAP", 1, 0, 1);
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
+    c->batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
+    c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 8192, 64, 262144) << 20;
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&l.shadow, hipStreamNonBlocking) != hipSuccess ||
@@ -1081,7 +1093,7 @@ int gpuart_hip_flush(gpuart_hip_ctx *c) {
     Scene sc = scene_of(c);
     TimedLaunch t;
     PassLane &l = c->lanes[c->next_lane];
-    c->next_lane = (c->next_lane + 1) % (uint32_t)c->lanes.size();
+    c->next_lane = (c->next_lane + 1) % c->lanes_in_use;
     const uint32_t nseg = segment_bound(c, p);
     l.pb.batch = (uint32_t)c->pend_seeds.size();
     SeedBatch seeds{};

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Renders K path-tracing passes of the bench workload (cfg3) with the GPUART_HIP_* knobs of the environment —
+the program to put behind `rocprofv3 ... --` when profiling one configuration.   python3 tools/run_passes.py [K]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from gpuart_amd import binding as B  # noqa: E402
+from gpuart_amd import synth_scenes as S  # noqa: E402
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+W, H = 1920, 1080
+cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
+r = B.Renderer(W, H, cam)
+r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+r.set_primitives(B.make_prims(S.scene_d()))
+r.set_max_path_segments(8)
+r.backend.set_mode(0)
+r.backend.set_timing(0)
+r.restart_path_tracing(1, K)
+t0 = time.perf_counter()
+for _ in range(K):
+    r.path_tracing_pass()
+r.finish()
+print("%d passes, %.3f ms/pass" % (K, (time.perf_counter() - t0) / K * 1e3))
+r.close()

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 from gpuart_amd import binding as B  # noqa: E402
 from gpuart_amd import synth_scenes as S  # noqa: E402
 
-W, H, K = 1920, 1080, 8
+W, H, K, REPS = 1920, 1080, int(os.environ.get("SWEEP_K", "24")), 3
 
 
 def run(cfg, prims, cam, mode=0):
@@ -29,13 +29,15 @@ def run(cfg, prims, cam, mode=0):
     r.restart_path_tracing(1, 2)
     r.path_tracing_pass(); r.path_tracing_pass()
     r.finish()
-    r.set_seed(5489)
-    r.restart_path_tracing(1, K)
-    t0 = time.perf_counter()
-    for _ in range(K):
-        r.path_tracing_pass()
-    r.finish()
-    dt = (time.perf_counter() - t0) / K * 1e3
+    dt = 1e9
+    for _ in range(REPS):  # best of REPS: neighbours on the box and clock ramps make single timings noisy
+        r.set_seed(5489)
+        r.restart_path_tracing(1, K)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            r.path_tracing_pass()
+        r.finish()
+        dt = min(dt, (time.perf_counter() - t0) / K * 1e3)
     acc = r.read_radiance(False)
     r.close()
     return dt, acc
