@@ -8,7 +8,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")  # see libgpuart_hip's request_
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("GPUART_LIBDIR") or os.path.join(HERE, "lib")  # override: A/B runs of differently built libraries
 HIP_LIB = os.path.join(LIBDIR, "libgpuart_hip.so")
 HOST_LIB = os.path.join(LIBDIR, "libgpuart.so")
 

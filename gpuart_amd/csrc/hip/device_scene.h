@@ -404,8 +404,11 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     // round trip per step).
     asm volatile("" : "+v"(q0.w), "+v"(q1.w));
     float el, eh;
-    bool hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
-    bool hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
+    bool hl, hh;
+    // (a version carrying both boxes' arithmetic in packed 2-wide vectors made the compiler turn the validity selects
+    // into scalar mask logic and ran 17 % slower — tools/ab.py)
+    hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
+    hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
     if (COUNT) wc->nodes++;  // the lower child's box test (the upper one is counted when the reference reaches it)
     if (COUNT || hh) {
         StackEntry e;

@@ -192,7 +192,12 @@ void Renderer::RenderDirectLighting() {
 
 void Renderer::ResetPathTracing() {
     PathTracing.numPathsRendered = 0;
-    if (Backend && Viewport.width) gpuart_hip_pt_reset(Backend);
+    if (Backend && Viewport.width) {
+        gpuart_hip_pt_reset(Backend);
+        // the passes RenderPathTracingPass() will submit until pathsPerPixel is reached (a scheduling hint)
+        const unsigned per = PathTracing.pathsPerPass ? PathTracing.pathsPerPass : 1;
+        gpuart_hip_pt_plan(Backend, (PathTracing.pathsPerPixel + per - 1) / per);
+    }
 }
 
 void Renderer::RestartPathTracing(unsigned pathsPerPass, unsigned pathsPerPixel) {

@@ -94,6 +94,11 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *ctx, const gpuart_params *p);
 /* Replaces the accumulator clear of Renderer::ResetPathTracing (reference src/renderer.cpp:490-500). */
 int gpuart_hip_pt_reset(gpuart_hip_ctx *ctx);
 
+/* Scheduling hint, no reference counterpart: how many gpuart_hip_pt_pass calls the caller expects to make before it
+ * observes the result (Renderer::RestartPathTracing knows it: pathsPerPixel / pathsPerPass, reference
+ * src/renderer.cpp:502-508). Sizes the pipeline runs the passes are grouped into; 0 = unknown. Never changes results. */
+int gpuart_hip_pt_plan(gpuart_hip_ctx *ctx, uint32_t passes);
+
 /* Replaces one pathTracing draw (reference src/renderer.cpp:534-599,
  * shaders/path_tracing.glsl:133-256): accum += radiance of `npaths` paths per pixel. */
 int gpuart_hip_pt_pass(gpuart_hip_ctx *ctx, const gpuart_params *p, const float randSeed[4], int npaths);
@@ -112,9 +117,10 @@ int gpuart_hip_write(gpuart_hip_ctx *ctx, int which, const float *rgba_host);
  * hands it to RCCL). Asynchronous on the context's stream; call gpuart_hip_finish before use. */
 int gpuart_hip_export(gpuart_hip_ctx *ctx, int which, void *rgba_device, float divide_by);
 
-/* glFlush() equivalent. gpuart_hip_pt_pass may only *collect* a pass: on small tiles several passes with identical
- * parameters are launched together as one batch (so that every kernel launch still has millions of paths), and up to
- * 8 batches are in flight at once on separate HIP streams; results are accumulated strictly in pass order. Everything
+/* glFlush() equivalent. gpuart_hip_pt_pass may only *collect* a pass: passes with identical parameters are launched
+ * together as one run of the pipeline (slot = pass x pixel, up to 16M paths, so that the persistent BVH-query waves take
+ * many rays per lane), and up to 8 runs are in flight at once on separate HIP streams (fewer when their path state would
+ * exceed 16 GB); results are accumulated strictly in pass order. Everything
  * that observes or changes state (read, export, finish, reset, set_camera, ...) flushes by itself. */
 int gpuart_hip_flush(gpuart_hip_ctx *ctx);
 

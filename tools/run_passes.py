@@ -10,6 +10,7 @@ from gpuart_amd import binding as B  # noqa: E402
 from gpuart_amd import synth_scenes as S  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 W, H = 1920, 1080
 cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
 r = B.Renderer(W, H, cam)
@@ -18,10 +19,11 @@ r.set_primitives(B.make_prims(S.scene_d()))
 r.set_max_path_segments(8)
 r.backend.set_mode(0)
 r.backend.set_timing(0)
-r.restart_path_tracing(1, K)
-t0 = time.perf_counter()
-for _ in range(K):
-    r.path_tracing_pass()
-r.finish()
-print("%d passes, %.3f ms/pass" % (K, (time.perf_counter() - t0) / K * 1e3))
+for _ in range(REPS):
+    r.restart_path_tracing(1, K)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        r.path_tracing_pass()
+    r.finish()
+    print("%d passes, %.3f ms/pass" % (K, (time.perf_counter() - t0) / K * 1e3))
 r.close()

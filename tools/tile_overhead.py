@@ -4,7 +4,7 @@ shows the fixed per-pass cost that limits strong scaling (ideal: t(N) = t(1)/N).
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from gpuart_amd import binding as B, sharding, synth_scenes as S
-W, H, K = 1920, 1080, 20
+W, H, K = 1920, 1080, int(os.environ.get("TILE_K", "64"))
 cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
 r = B.Renderer(W, H, cam)
 r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
@@ -12,7 +12,7 @@ r.set_primitives(B.make_prims(S.scene_d()))
 r.set_max_path_segments(8)
 r.backend.set_timing(0)
 t1 = None
-for n in (1, 2, 4, 8):
+for n in [int(x) for x in os.environ.get("TILE_N", "1,2,4,8").split(",")]:
     worst = 0
     for rank in sorted(set([0, n - 1])):
         if n > 1:
