@@ -205,6 +205,12 @@ class Backend:
     def pt_reset(self):
         self._chk(self.L.gpuart_hip_pt_reset(self.ctx))
 
+    def pt_plan(self, passes):
+        self._chk(self.L.gpuart_hip_pt_plan(self.ctx, C.c_uint32(passes)))
+
+    def flush(self):
+        self._chk(self.L.gpuart_hip_flush(self.ctx))
+
     def pt_pass(self, params, rand_seed, npaths):
         rs = (C.c_float * 4)(*[float(x) for x in rand_seed])
         self._chk(self.L.gpuart_hip_pt_pass(self.ctx, C.byref(params), rs, C.c_int(npaths)))

@@ -154,16 +154,17 @@ GD_FN V2 v2(float a, float b) { V2 r; r.x = a; r.y = b; return r; }
 /// (du+dv)*invDet form and dot3's order; the pair is carried in 2-wide vectors so that the multiplies and
 /// adds become packed instructions). Straight-line: every rejection is a term of one predicate; a rejected
 /// triangle yields -1, and so does one closer than VISIBILITY_OFFSET (bvh_intersection.glsl:216-217).
-GD_FN V2 triangle_pair_t(const Ray &r, float4 a0, float4 a1, float4 a2, float4 b0, float4 b1, float4 b2) {
+GD_FN V2 triangle_pair_t(float rox, float roy, float roz, float rdx, float rdy, float rdz, float4 a0, float4 a1, float4 a2, float4 b0, float4 b1, float4 b2) {
     const V2 v0x = v2(a0.x, b0.x), v0y = v2(a0.y, b0.y), v0z = v2(a0.z, b0.z);
     const V2 e1x = v2(a1.x, b1.x), e1y = v2(a1.y, b1.y), e1z = v2(a1.z, b1.z);
     const V2 e2x = v2(a2.x, b2.x), e2y = v2(a2.y, b2.y), e2z = v2(a2.z, b2.z);
-    const V2 dx = v2(r.d.x, r.d.x), dy = v2(r.d.y, r.d.y), dz = v2(r.d.z, r.d.z);
+    // (scalars, not F3: a by-value aggregate read in differently shaped pieces stays in scratch)
+    const V2 dx = v2(rdx, rdx), dy = v2(rdy, rdy), dz = v2(rdz, rdz);
     // pvec = cross(rdir, edge2)
     const V2 px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
     const V2 det = (e1z * pz + e1y * py) + e1x * px;
     V2 inv; inv.x = 1 / det.x; inv.y = 1 / det.y;
-    const V2 tx = v2(r.o.x, r.o.x) - v0x, ty = v2(r.o.y, r.o.y) - v0y, tz = v2(r.o.z, r.o.z) - v0z;
+    const V2 tx = v2(rox, rox) - v0x, ty = v2(roy, roy) - v0y, tz = v2(roz, roz) - v0z;
     const V2 du = (tz * pz + ty * py) + tx * px;
     const V2 u = du * inv;
     // qvec = cross(tvec, edge1)
@@ -186,12 +187,17 @@ GD_FN V2 triangle_pair_t(const Ray &r, float4 a0, float4 a1, float4 a2, float4 b
 
 /// One primitive record against a ray (reference CheckBVHPrimitiveIntersection,
 /// shaders/bvh_intersection.glsl:125-223, including its `pos < VISIBILITY_OFFSET -> -1` cut).
+/// TYPES: bit t set = primitives of type t may occur (the uploader knows which types a scene holds; code for absent
+/// types is not generated, which is worth 15 VGPRs — a fifth wave per SIMD — in the BVH-query kernel).
+#define GD_ALL_TYPES 0xF
+template <int TYPES = GD_ALL_TYPES>
 GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F3 &p, F3 &n, int &ptype) {
     ptype = (int)(__float_as_uint(q0.w) & 3u);
-    if (ptype == P_TRIANGLE) triangle_hit(r, xyz(q0), xyz(q1), xyz(q2), pos, p, n);
-    else if (ptype == P_SPHERE) sphere_hit(r, xyz(q0), q1.x, pos, p, n);
-    else if (ptype == P_DISC) disc_hit(r, xyz(q0), q1.w, xyz(q1), pos, p, n);
-    else cone_hit(r, xyz(q0), q2.x, xyz(q1), q1.w, q2.y, q2.z, q2.w, pos, p, n);
+    pos = -1; p = f3(0, 0, 0); n = f3(0, 0, 0);
+    if ((TYPES >> P_TRIANGLE & 1) && ptype == P_TRIANGLE) triangle_hit(r, xyz(q0), xyz(q1), xyz(q2), pos, p, n);
+    else if ((TYPES >> P_SPHERE & 1) && ptype == P_SPHERE) sphere_hit(r, xyz(q0), q1.x, pos, p, n);
+    else if ((TYPES >> P_DISC & 1) && ptype == P_DISC) disc_hit(r, xyz(q0), q1.w, xyz(q1), pos, p, n);
+    else if ((TYPES >> P_CONE & 1) && ptype == P_CONE) cone_hit(r, xyz(q0), q2.x, xyz(q1), q1.w, q2.y, q2.z, q2.w, pos, p, n);
     if (pos < GD_VISIBILITY_OFFSET) pos = -1;
 }
 
@@ -235,7 +241,7 @@ GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos) {
 /// Tests the primitives of the leaf starting at primitive `first` (its count sits in the first record's
 /// type word); keeps the strictly closer hit (the first one wins ties, reference
 /// shaders/bvh_intersection.glsl:405-423). Returns true if ANY_HIT and something was hit.
-template <bool ANY_HIT, bool COUNT>
+template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES>
 GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
     uint32_t count = 1;
     for (uint32_t i = 0; i < count; i++) {
@@ -246,7 +252,7 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &close
             if (count == 0) break;  // empty leaf (empty scene)
         }
         float pos; F3 p, n; int ptype;
-        prim_hit(r, q0, q1, q2, pos, p, n, ptype);
+        prim_hit<TYPES>(r, q0, q1, q2, pos, p, n, ptype);
         if (COUNT) wc->prims[ptype & 3]++;
         if (pos > 0 && pos < closest) {
             closest = pos;
@@ -268,7 +274,7 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, float &
     const float4 *pb = count > 1 ? pa + 3 : pa;
     float4 a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
     if (COUNT) wc->prims[P_TRIANGLE] += count;
-    V2 t = triangle_pair_t(r, a0, a1, a2, b0, b1, b2);
+    V2 t = triangle_pair_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, a0, a1, a2, b0, b1, b2);
     if (t.x > 0 && t.x < closest) {
         closest = t.x;
         hit_prim = first;
@@ -423,11 +429,11 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
 }
 
 /// Tests the primitives of the pending leaf, then pops. Precondition: state == LEAF or LEAF_TRIS.
-template <bool ANY_HIT, bool COUNT>
+template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES>
 GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
     bool stop;
     if (t.state == TRAV_LEAF_TRIS) stop = leaf_test_tris<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc);
-    else stop = leaf_test<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc);
+    else stop = leaf_test<ANY_HIT, COUNT, TYPES>(sc, r, t.node, t.closest, t.hit_prim, wc);
     if (stop && ANY_HIT) {
         t.state = TRAV_DONE;
         return;

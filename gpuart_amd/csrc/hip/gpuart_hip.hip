@@ -162,11 +162,15 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
 // A lane that finishes its ray takes the next one from the queue (wave-local chunk, one atomic per
 // FETCH_CHUNK rays), so all 64 lanes keep traversing; box tests and leaf tests are issued as separate
 // wave-wide phases (leaf code waits until LEAF_LANES lanes need it).
+#define GD_FLAT_TYPES ((1 << gd::P_DISC) | (1 << gd::P_TRIANGLE))
 #ifndef GD_TRACE_WAVES
-#define GD_TRACE_WAVES 1
+#define GD_TRACE_WAVES 5  // 5 waves per SIMD (<= 96 VGPRs): +4.5 % over the unconstrained 103-VGPR build (tools/ab.py)
 #endif
-template <bool SHADOW, bool ANY, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
+#ifndef GD_TRACE_WAVES_LEAN
+#define GD_TRACE_WAVES_LEAN 6  // the lean kernels need 88 VGPRs: a sixth wave costs a few spilled registers and still gains 1.7 %
+#endif
+template <bool SHADOW, bool ANY, bool COUNT, int TYPES>
+__global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES_LEAN : GD_TRACE_WAVES) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
                                                  int npaths, float4 *accum, uint4 *spill, unsigned long long *gcounters,
                                                  TraceTuning tune) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_trace(Scene sc, Frame
             unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
             if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
                 if (slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS))
-                    trav_step_leaf<ANY, COUNT>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                    trav_step_leaf<ANY, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                 descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
                 at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             }
@@ -546,6 +550,7 @@ struct gpuart_hip_ctx {
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
     size_t batch_paths = (size_t)16 << 20;  ///< passes are batched while one pipeline run stays within this many paths
     size_t min_run_paths = (size_t)2 << 20;  ///< a pipeline run is not made smaller than this many paths
+    bool lean_kernels = true;      ///< use the BVH-query kernels specialised for the primitive types present
     uint32_t planned_passes = 0;   ///< gpuart_hip_pt_plan hint (0: unknown)
     size_t run_passes = 1;         ///< passes per pipeline run (see plan_runs)
     uint32_t lanes_in_use = 1;     ///< pass lanes cycled through (all of them unless their path state would exceed lane_budget)
@@ -925,6 +930,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
     c->batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
+    c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
     c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
     for (auto &l : c->lanes) {
@@ -1121,6 +1127,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     if ((r = ensure_segment_counters(c, l, nseg))) return r;
     const PathBuffers &b = l.pb;
     const bool refwork = c->mode == 1;
+    const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots * b.batch / BLOCK));
@@ -1133,8 +1140,9 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         for (uint32_t seg = 0; seg < nseg; seg++) {
             TimedLaunch tt;
             if (detail && (r = begin_timed(c, tt, 1, l.main))) return r;
-            if (refwork) k_trace<false, false, true><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-            else k_trace<false, false, false><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+            if (refwork) k_trace<false, false, true, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+            else if (flat_only) k_trace<false, false, false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+            else k_trace<false, false, false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
             if (detail && (r = end_timed(c, tt, l.main))) return r;
             if (shadow_pending >= 0) {  // the previous segment's shadow pass updates pathColor, which shading reads
                 HIP_TRY(hipStreamWaitEvent(l.main, l.ev_shadowed[shadow_pending], 0));
@@ -1152,8 +1160,9 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
                     HIP_TRY(hipStreamWaitEvent(ss, l.ev_shaded[seg], 0));
                 }
                 if (detail && (r = begin_timed(c, tt, 1, ss))) return r;
-                if (refwork) k_trace<true, false, true><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
-                else k_trace<true, true, false><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
+                if (refwork) k_trace<true, false, true, GD_ALL_TYPES><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
+                else if (flat_only) k_trace<true, true, false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
+                else k_trace<true, true, false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
                 if (detail && (r = end_timed(c, tt, ss))) return r;
                 if (c->overlap) {
                     HIP_TRY(hipEventRecord(l.ev_shadowed[seg], ss));
