@@ -550,6 +550,7 @@ struct gpuart_hip_ctx {
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
     size_t batch_paths = (size_t)16 << 20;  ///< passes are batched while one pipeline run stays within this many paths
     size_t min_run_paths = (size_t)2 << 20;  ///< a pipeline run is not made smaller than this many paths
+    uint32_t plan_runs_target = 5; ///< a planned sequence of passes is cut into about this many equal runs
     bool lean_kernels = true;      ///< use the BVH-query kernels specialised for the primitive types present
     uint32_t planned_passes = 0;   ///< gpuart_hip_pt_plan hint (0: unknown)
     size_t run_passes = 1;         ///< passes per pipeline run (see plan_runs)
@@ -598,7 +599,7 @@ namespace {
 void plan_runs(gpuart_hip_ctx *c) {
     if (!c->n_slots) { c->run_passes = 1; return; }
     const size_t min_run = std::max<size_t>(1, c->min_run_paths / c->n_slots);
-    size_t want = c->planned_passes ? (c->planned_passes + 4) / 5 : std::max<size_t>(1, ((size_t)8 << 20) / c->n_slots);
+    size_t want = c->planned_passes ? (c->planned_passes + c->plan_runs_target - 1) / c->plan_runs_target : std::max<size_t>(1, ((size_t)8 << 20) / c->n_slots);
     c->run_passes = std::min<size_t>(c->max_batch, std::max(min_run, want));
 }
 int realloc_tile(gpuart_hip_ctx *c) {
@@ -930,6 +931,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
     c->batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
+    c->plan_runs_target = env_u32("GPUART_HIP_PLAN_RUNS", 5, 1, 32);
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
     c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
