@@ -147,42 +147,24 @@ GD_FN void cone_hit(const Ray &r, F3 c1, float r1, F3 ax, float axLen, float wid
     }
 }
 
-typedef float V2 __attribute__((ext_vector_type(2)));
-GD_FN V2 v2(float a, float b) { V2 r; r.x = a; r.y = b; return r; }
-
-/// Ray parameters of TWO triangles at once (lane-wise the arithmetic of triangle.glsl:50-76, including the
-/// (du+dv)*invDet form and dot3's order; the pair is carried in 2-wide vectors so that the multiplies and
-/// adds become packed instructions). Straight-line: every rejection is a term of one predicate; a rejected
-/// triangle yields -1, and so does one closer than VISIBILITY_OFFSET (bvh_intersection.glsl:216-217).
-GD_FN V2 triangle_pair_t(float rox, float roy, float roz, float rdx, float rdy, float rdz, float4 a0, float4 a1, float4 a2, float4 b0, float4 b1, float4 b2) {
-    const V2 v0x = v2(a0.x, b0.x), v0y = v2(a0.y, b0.y), v0z = v2(a0.z, b0.z);
-    const V2 e1x = v2(a1.x, b1.x), e1y = v2(a1.y, b1.y), e1z = v2(a1.z, b1.z);
-    const V2 e2x = v2(a2.x, b2.x), e2y = v2(a2.y, b2.y), e2z = v2(a2.z, b2.z);
-    // (scalars, not F3: a by-value aggregate read in differently shaped pieces stays in scratch)
-    const V2 dx = v2(rdx, rdx), dy = v2(rdy, rdy), dz = v2(rdz, rdz);
-    // pvec = cross(rdir, edge2)
-    const V2 px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
-    const V2 det = (e1z * pz + e1y * py) + e1x * px;
-    V2 inv; inv.x = 1 / det.x; inv.y = 1 / det.y;
-    const V2 tx = v2(rox, rox) - v0x, ty = v2(roy, roy) - v0y, tz = v2(roz, roz) - v0z;
-    const V2 du = (tz * pz + ty * py) + tx * px;
-    const V2 u = du * inv;
-    // qvec = cross(tvec, edge1)
-    const V2 qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
-    const V2 dv = (dz * qz + dy * qy) + dx * qx;
-    const V2 v = dv * inv;
-    const V2 w = (du + dv) * inv;
-    const V2 t = ((e2z * qz + e2y * qy) + e2x * qx) * inv;
-    V2 out;
-    {
-        bool ok = !(fabsf(det.x) < 1.0e-10f) & !(u.x < 0) & !(u.x > 1) & !(v.x < 0) & !(w.x > 1) & !(t.x < GD_VISIBILITY_OFFSET);
-        out.x = ok ? t.x : -1.0f;
-    }
-    {
-        bool ok = !(fabsf(det.y) < 1.0e-10f) & !(u.y < 0) & !(u.y > 1) & !(v.y < 0) & !(w.y > 1) & !(t.y < GD_VISIBILITY_OFFSET);
-        out.y = ok ? t.y : -1.0f;
-    }
-    return out;
+/// Ray parameter of one triangle record (the arithmetic of triangle.glsl:50-76, including the (du+dv)*invDet form and
+/// dot3's order). Straight-line: every rejection is a term of one predicate; a rejected triangle yields -1, and so does
+/// one closer than VISIBILITY_OFFSET (bvh_intersection.glsl:216-217). A version that carried the two triangles of a leaf
+/// in packed 2-wide vectors (v_pk_mul/add_f32) was 2 % slower than two of these (tools/ab.py).
+GD_FN float triangle_t(float rox, float roy, float roz, float rdx, float rdy, float rdz, float4 a0, float4 a1, float4 a2) {
+    const float px = rdy * a2.z - rdz * a2.y, py = rdz * a2.x - rdx * a2.z, pz = rdx * a2.y - rdy * a2.x;
+    const float det = (a1.z * pz + a1.y * py) + a1.x * px;
+    const float inv = 1 / det;
+    const float tx = rox - a0.x, ty = roy - a0.y, tz = roz - a0.z;
+    const float du = (tz * pz + ty * py) + tx * px;
+    const float u = du * inv;
+    const float qx = ty * a1.z - tz * a1.y, qy = tz * a1.x - tx * a1.z, qz = tx * a1.y - ty * a1.x;
+    const float dv = (rdz * qz + rdy * qy) + rdx * qx;
+    const float v = dv * inv;
+    const float w = (du + dv) * inv;
+    const float t = ((a2.z * qz + a2.y * qy) + a2.x * qx) * inv;
+    bool ok = !(fabsf(det) < 1.0e-10f) & !(u < 0) & !(u > 1) & !(v < 0) & !(w > 1) & !(t < GD_VISIBILITY_OFFSET);
+    return ok ? t : -1.0f;
 }
 
 /// One primitive record against a ray (reference CheckBVHPrimitiveIntersection,
@@ -274,14 +256,15 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, float &
     const float4 *pb = count > 1 ? pa + 3 : pa;
     float4 a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
     if (COUNT) wc->prims[P_TRIANGLE] += count;
-    V2 t = triangle_pair_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, a0, a1, a2, b0, b1, b2);
-    if (t.x > 0 && t.x < closest) {
-        closest = t.x;
+    const float ta = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, a0, a1, a2);
+    const float tb = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, b0, b1, b2);
+    if (ta > 0 && ta < closest) {
+        closest = ta;
         hit_prim = first;
         if (ANY_HIT) return true;
     }
-    if (t.y > 0 && t.y < closest) {
-        closest = t.y;
+    if (tb > 0 && tb < closest) {
+        closest = tb;
         hit_prim = first + 1;  // only reachable with count == 2
         if (ANY_HIT) return true;
     }
