@@ -922,7 +922,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
         return (uint32_t)std::min<long>(hi, std::max<long>(lo, x));
     };
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 6, 1, 32);  // persistent grids of one-wave workgroups
+    c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 8, 1, 32);  // persistent grids of one-wave workgroups
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
