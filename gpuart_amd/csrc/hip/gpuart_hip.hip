@@ -50,7 +50,7 @@ struct PathBuffers {
 };
 
 #define MAX_BATCH 64
-/// RandSeed of every pass of a batch (passes are batched so that small tiles still fill the GPU).
+/// RandSeed of every pass of a pipeline run (slot = pass x pixel; up to 16M paths or MAX_BATCH passes per run).
 struct SeedBatch {
     float4 seed[MAX_BATCH];
 };
@@ -546,7 +546,7 @@ struct gpuart_hip_ctx {
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
     TraceTuning tune{64, 16, 16};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
-    uint32_t max_batch = 1;        ///< passes batched into one run of the pipeline (small tiles: up to MAX_BATCH)
+    uint32_t max_batch = 1;        ///< most passes one run of the pipeline may hold (batch_paths / tile slots, <= MAX_BATCH)
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
     size_t batch_paths = (size_t)16 << 20;  ///< passes are batched while one pipeline run stays within this many paths
     size_t min_run_paths = (size_t)2 << 20;  ///< a pipeline run is not made smaller than this many paths
@@ -1223,7 +1223,7 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
         HIP_TRY(hipGetLastError());
         return end_timed(c, t);
     }
-    // Passes are collected and launched max_batch at a time (1 for large tiles). A pass with different parameters
+    // Passes are collected and launched run_passes at a time (plan_runs). A pass with different parameters
     // starts a new batch; anything that observes or changes state flushes first.
     if (!c->pend_seeds.empty() && (memcmp(&c->pend_params, p, sizeof *p) != 0 || c->pend_npaths != npaths))
         if ((r = gpuart_hip_flush(c))) return r;
