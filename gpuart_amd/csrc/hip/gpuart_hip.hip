@@ -623,19 +623,34 @@ int realloc_tile(gpuart_hip_ctx *c) {
     // paths: a persistent k_trace wave then takes many rays per lane, and the drain at the end of every launch — waves
     // finishing their last, long rays with few lanes busy — shrinks relative to the useful work (SQ_INSTS_VALU per
     // ray falls by a quarter from 2M to 16M paths per launch at 1080p).
-    const size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, c->batch_paths / n));
+    size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, c->batch_paths / n));
     if (n * B > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
-    c->max_batch = (uint32_t)B;
-    plan_runs(c);
-    const size_t bytes = n * B * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + B * c->tile_pixels * sizeof(float4);
-    c->lanes_in_use = (uint32_t)std::min<size_t>(c->lanes.size(), std::max<size_t>(2, c->lane_budget / bytes));
-    c->next_lane = 0;
-    for (size_t li = 0; li < c->lanes.size(); li++) {
-        PassLane &l = c->lanes[li];
+    for (auto &l : c->lanes) {
         if (l.pathmem) { (void)hipFree(l.pathmem); l.pathmem = nullptr; }
         l.used = false;
-        if (li >= c->lanes_in_use) continue;
-        HIP_TRY(hipMalloc(&l.pathmem, bytes));
+    }
+    c->next_lane = 0;
+    // Lanes within the memory budget; when the device cannot give that much (other tenants), fewer lanes and then
+    // smaller runs are tried before giving up — results do not depend on either.
+    size_t lanes = 0, bytes = 0;
+    for (;;) {
+        bytes = n * B * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + B * c->tile_pixels * sizeof(float4);
+        if (!lanes) lanes = std::min<size_t>(c->lanes.size(), std::max<size_t>(2, c->lane_budget / bytes));
+        size_t got = 0;
+        while (got < lanes && hipMalloc(&c->lanes[got].pathmem, bytes) == hipSuccess) got++;
+        if (got == lanes) break;
+        (void)hipGetLastError();  // clear the out-of-memory error
+        for (size_t li = 0; li < got; li++) { (void)hipFree(c->lanes[li].pathmem); c->lanes[li].pathmem = nullptr; }
+        if (lanes > 2) lanes = std::max<size_t>(2, lanes / 2);
+        else if (B > 1) { B = (B + 1) / 2; lanes = 0; }
+        else if (lanes > 1) lanes = 1;
+        else return fail(GPUART_HIP_ERR_DEVICE, "out of device memory for the path state of one pass");
+    }
+    c->max_batch = (uint32_t)B;
+    c->lanes_in_use = (uint32_t)lanes;
+    plan_runs(c);
+    for (size_t li = 0; li < lanes; li++) {
+        PassLane &l = c->lanes[li];
         char *m = (char *)l.pathmem;
         PathBuffers &b = l.pb;
         const size_t nb = n * B;

@@ -583,6 +583,40 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan):
         assert_bits(grouped[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "vs oracle")
 
 
+@pytest.mark.parametrize("env", [
+    {"GPUART_HIP_LANE_BUDGET_MB": "64", "GPUART_HIP_BATCH_MPATHS": "1"},
+    {"GPUART_HIP_PASSES_IN_FLIGHT": "1", "GPUART_HIP_MAX_BATCH": "3", "GPUART_HIP_LEAN_KERNELS": "0"},
+    {"GPUART_HIP_WAVES_PER_CU": "1", "GPUART_HIP_CHUNK": "16", "GPUART_HIP_REFILL_LANES": "1", "GPUART_HIP_LEAF_LANES": "64",
+     "GPUART_HIP_OVERLAP": "0", "GPUART_HIP_PLAN_RUNS": "32"},
+])
+def test_scheduling_knobs_never_change_the_result(B, O, env, monkeypatch):
+    """Memory budget, lanes in flight, run sizes, persistent-grid size, refill / leaf thresholds, kernel specialisation:
+    none of the tuning knobs may change a bit of the accumulator (Scene D tile, 12 passes, vs the oracle)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H = 192, 96
+    cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    tree, _ = O.build_bvh(scene("scene_d"))
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 8, 0.01)
+    K = 12
+    seeds = O.randseeds(K)
+    acc = np.zeros((H, W, 4), np.float32)
+    for k in range(K):
+        O.pt_pass(tree, c, W, H, P, seeds[k], 1, acc, nthreads=8)
+    b = B.Backend(0)
+    try:
+        b.resize(W, H); b.upload_bvh(tree); b.set_camera(c)
+        b.pt_reset(); b.pt_plan(K)
+        for k in range(K):
+            b.pt_pass(to_params(B, P), seeds[k], 1)
+        got = b.read(1)
+    finally:
+        b.close()
+    assert_bits(got[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "knobs %s" % env)
+
+
 def test_checkpoint_resume_is_bit_identical(B, tmp_path):
     """8 passes == 3 passes + SaveCheckpoint + (new Renderer) LoadCheckpoint + 5 passes, including the RNG state."""
     cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
