@@ -544,7 +544,7 @@ struct gpuart_hip_ctx {
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
-    TraceTuning tune{64, 16, 16};
+    TraceTuning tune{128, 16, 16};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
     uint32_t max_batch = 1;        ///< most passes one run of the pipeline may hold (batch_paths / tile slots, <= MAX_BATCH)
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
@@ -938,7 +938,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     };
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 8, 1, 32);  // persistent grids of one-wave workgroups
-    c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 64, 16, 4096);
+    c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 128, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
