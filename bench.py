@@ -21,7 +21,7 @@ import os
 import sys
 import time
 
-# The renderer keeps up to 8 pipeline runs in flight on 17 HIP streams; with ROCm's default of 4 hardware queues their kernels would
+# The renderer keeps up to 8 pipeline runs in flight on 9 HIP streams; with ROCm's default of 4 hardware queues their kernels would
 # serialise. Must be set before the HIP runtime initialises (i.e. before torch is imported). See DESIGN.md §4.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 

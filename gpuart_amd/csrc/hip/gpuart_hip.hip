@@ -155,30 +155,34 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
     if (blockIdx.x == 0 && threadIdx.x == 0) b.counters[0] = no_segments ? 0u : total;
 }
 
-// ---- wavefront stage 1/3: BVH queries for a whole queue, persistent waves with lane refill -----------
-// SHADOW = false: closest-hit query of segment `seg` for every slot of queue[seg&1]; result -> hit[slot].
-// SHADOW = true : Sun shadow query for every slot of shadow_queue; applies the Sun term and, for paths
-//                 that end with this segment, commits the path.
-// A lane that finishes its ray takes the next one from the queue (wave-local chunk, one atomic per
-// FETCH_CHUNK rays), so all 64 lanes keep traversing; box tests and leaf tests are issued as separate
-// wave-wide phases (leaf code waits until LEAF_LANES lanes need it).
+// ---- wavefront stage 1/3: BVH queries, persistent waves with lane refill ----------------------------------
+// One launch serves two queues at once: the closest-hit queries of segment `seg_c` (slots of queue[seg_c&1]; result ->
+// hit[slot]) and the Sun-shadow queries of segment `seg_s` (slots of shadow_queue; they apply the Sun term and, for
+// paths that end with that segment, commit the path) — after shading segment s both the shadow queries of s and the
+// closest-hit queries of s+1 are ready and touch disjoint data. Either may be absent (-1). The long closest-hit rays
+// come first in the combined index space, the short shadow rays (they stop at the first accepted hit when
+// `any_shadow`) fill the end of the launch.
+// A lane that finishes its ray takes the next one from the queue (wave-local chunk, one atomic per chunk), so all
+// 64 lanes keep traversing; box tests and leaf tests are issued as separate wave-wide phases (leaf code waits until
+// LEAF_LANES lanes need it).
 #define GD_FLAT_TYPES ((1 << gd::P_DISC) | (1 << gd::P_TRIANGLE))
 #ifndef GD_TRACE_WAVES
-#define GD_TRACE_WAVES 5  // 5 waves per SIMD (<= 96 VGPRs): +4.5 % over the unconstrained 103-VGPR build (tools/ab.py)
+#define GD_TRACE_WAVES 5  // waves per SIMD the register allocation must allow (<= 96 VGPRs)
 #endif
 #ifndef GD_TRACE_WAVES_LEAN
-#define GD_TRACE_WAVES_LEAN 6  // the lean kernels need 88 VGPRs: a sixth wave costs a few spilled registers and still gains 1.7 %
+#define GD_TRACE_WAVES_LEAN 6  // the kernels without cone / sphere code fit 6 waves per SIMD (<= 80 VGPRs)
 #endif
-template <bool SHADOW, bool ANY, bool COUNT, int TYPES>
-__global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES_LEAN : GD_TRACE_WAVES) k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg, int j,
-                                                 int npaths, float4 *accum, uint4 *spill, unsigned long long *gcounters,
-                                                 TraceTuning tune) {
+template <bool COUNT, int TYPES>
+__global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES_LEAN : GD_TRACE_WAVES)
+k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s, int any_shadow, int j, int npaths, float4 *accum,
+        uint4 *spill, unsigned long long *gcounters, TraceTuning tune) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    const uint32_t *queue = SHADOW ? b.shadow_queue : b.queue[seg & 1];
-    const uint32_t n = b.counters[4 * seg + (SHADOW ? 2 : 0)];
-    uint32_t *cursor = &b.counters[4 * seg + (SHADOW ? 3 : 1)];
+    const uint32_t *queue_c = b.queue[seg_c & 1];
+    const uint32_t n_c = seg_c >= 0 ? b.counters[4 * seg_c] : 0u;
+    const uint32_t n = n_c + (seg_s >= 0 ? b.counters[4 * seg_s + 2] : 0u);
+    uint32_t *cursor = &b.counters[seg_c >= 0 ? 4 * seg_c + 1 : 4 * seg_s + 3];
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     WorkCounters wc = {0, 0, {0, 0, 0, 0}};
 
@@ -188,6 +192,7 @@ __global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES
     uint32_t chunk_next = min(blockIdx.x * tune.chunk, n), chunk_end = min((blockIdx.x + 1) * tune.chunk, n);  // wave-uniform
     bool exhausted = false;                                                                                   // wave-uniform
     uint32_t slot = SLOT_INVALID;
+    bool shadow = false;                    // this lane's ray is a Sun-shadow query
     F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0);  // the ray (two F3 locals: a long-lived Ray aggregate ends up in scratch)
     F3 rdiv = f3(1, 1, 1);
     Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
@@ -208,11 +213,14 @@ __global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES
             uint32_t want = (uint32_t)__popcll(idle), take = min(want, chunk_end - chunk_next);
             uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1));
             if (slot == SLOT_INVALID && rank < take) {
-                uint32_t s = queue[chunk_next + rank];
+                const uint32_t i = chunk_next + rank;
+                const bool sh = i >= n_c;
+                uint32_t s = sh ? b.shadow_queue[i - n_c] : queue_c[i];
                 if (s != SLOT_INVALID) {
                     slot = s;
+                    shadow = sh;
                     ro = xyz(b.ray_o[s]);
-                    rd = SHADOW ? sun : xyz(b.ray_d[s]);
+                    rd = sh ? sun : xyz(b.ray_d[s]);
                     rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                     trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
                 }
@@ -231,8 +239,11 @@ __global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES
             unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
             if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
-                if (slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS))
-                    trav_step_leaf<ANY, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                if (slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS)) {
+                    trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                    // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
+                    if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
+                }
                 descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
                 at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
             }
@@ -242,7 +253,7 @@ __global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES
         }
         // ---- retire finished rays
         if (slot != SLOT_INVALID && t.state == TRAV_DONE) {
-            if (!SHADOW) {
+            if (!shadow) {
                 b.hit[slot] = make_uint2(__float_as_uint(t.closest), t.hit_prim);
             } else {
                 float4 term = b.sun[slot];
@@ -475,7 +486,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// Passes in flight live on 2 streams each (+ the primary stream). ROCm maps HIP streams onto GPU_MAX_HW_QUEUES
+// Every pipeline run in flight has its own stream (+ the primary stream). ROCm maps HIP streams onto GPU_MAX_HW_QUEUES
 // hardware queues (default 4) and kernels of streams that share a queue serialise, which would undo the overlap
 // the pass lanes exist for; ask for more queues unless the user has chosen a value. Must happen before the HIP
 // runtime initialises, hence a load-time constructor (bench.py also sets it before importing torch).
@@ -515,18 +526,16 @@ struct TimedLaunch {
 
 }  // namespace
 
-/// Everything one path-tracing pass needs while it is in flight. Several passes are in flight at once (each on its
-/// own pair of streams); their kernels fill each other's tails, which matters most for small tiles (multi-GPU).
+/// Everything one run of the pipeline (a group of path-tracing passes) needs while it is in flight. Several runs are in
+/// flight at once, each on its own stream; their kernels fill each other's tails.
 struct PassLane {
-    hipStream_t main = nullptr;    ///< gen / closest-hit queries / shading
-    hipStream_t shadow = nullptr;  ///< Sun-shadow queries of segment s, beside the closest-hit queries of s+1
-    PathBuffers pb{};              ///< wavefront path state (tile-sized)
+    hipStream_t main = nullptr;    ///< every kernel of the run, in order
+    PathBuffers pb{};              ///< wavefront path state (passes of the run x tile slots)
     void *pathmem = nullptr;
-    float4 *passcolor = nullptr;   ///< this pass's colour per pixel, added to the accumulator by k_accumulate
-    uint4 *spill_main = nullptr, *spill_shadow = nullptr;  ///< traversal-stack overflow, one per stream
+    float4 *passcolor = nullptr;   ///< colour per pass and pixel, added to the accumulator by k_accumulate
+    uint4 *spill_main = nullptr;   ///< traversal-stack overflow of the lane's BVH-query launches
     uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
-    std::vector<hipEvent_t> ev_shaded, ev_shadowed;  ///< per segment: shading done (main) / shadow pass done (shadow)
-    hipEvent_t ev_done = nullptr;  ///< the pass has finished (main stream)
+    hipEvent_t ev_done = nullptr;  ///< the run has finished (main stream)
     hipEvent_t ev_free = nullptr;  ///< its colour has been accumulated (primary stream): the lane may be reused
     bool used = false;
 };
@@ -540,7 +549,6 @@ struct gpuart_hip_ctx {
     uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow for kernels on the primary stream
     std::vector<PassLane> lanes;
     uint32_t next_lane = 0;
-    int overlap = 1;               ///< run shadow queries beside the next closest-hit queries
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
@@ -550,7 +558,7 @@ struct gpuart_hip_ctx {
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
     size_t batch_paths = (size_t)16 << 20;  ///< passes are batched while one pipeline run stays within this many paths
     size_t min_run_paths = (size_t)2 << 20;  ///< a pipeline run is not made smaller than this many paths
-    uint32_t plan_runs_target = 5; ///< a planned sequence of passes is cut into about this many equal runs
+    double plan_run_factor = 0.75; ///< run length = this x sqrt(planned work), in units of 2M paths (plan_runs)
     bool lean_kernels = true;      ///< use the BVH-query kernels specialised for the primitive types present
     uint32_t planned_passes = 0;   ///< gpuart_hip_pt_plan hint (0: unknown)
     size_t run_passes = 1;         ///< passes per pipeline run (see plan_runs)
@@ -583,7 +591,6 @@ namespace {
 int drain(gpuart_hip_ctx *c) {
     for (auto &l : c->lanes) {
         if (l.main) HIP_TRY(hipStreamSynchronize(l.main));
-        if (l.shadow) HIP_TRY(hipStreamSynchronize(l.shadow));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -593,15 +600,25 @@ int drain(gpuart_hip_ctx *c) {
 extern "C" int gpuart_hip_flush(gpuart_hip_ctx *c);
 namespace {
 
-/// Passes per pipeline run. Equal runs that start together finish together, so a sequence of K passes is cut into about
-/// five runs (K/5 passes each; measured on cfg3: K = 20 -> 4 passes per run 1.30 ms/pass against 1.53 with runs of 8),
-/// never below ~2M paths and never above max_batch (16M paths); with no plan, 8M paths.
+/// Passes per pipeline run. Runs should be long (a persistent launch that takes many rays per lane wastes less of its
+/// instructions on draining its last rays) and numerous (their kernels fill each other's tails, and more runs than lanes
+/// keeps the lanes out of step). For a planned sequence of u units of work (1 unit = 2M paths, one 1080p pass) the best
+/// run length measured on cfg3 was 1, 1, 2-3, 3-4, 6 units for u = 2, 4, 8, 20, 64 — about 0.75 sqrt(u); never below
+/// `min_run_paths`, never above max_batch (16M paths). Without a plan: 8M paths.
 void plan_runs(gpuart_hip_ctx *c) {
     if (!c->n_slots) { c->run_passes = 1; return; }
+    const double unit = (double)((size_t)2 << 20);
     const size_t min_run = std::max<size_t>(1, c->min_run_paths / c->n_slots);
-    size_t want = c->planned_passes ? (c->planned_passes + c->plan_runs_target - 1) / c->plan_runs_target : std::max<size_t>(1, ((size_t)8 << 20) / c->n_slots);
+    size_t want;
+    if (c->planned_passes) {
+        const double u = (double)c->planned_passes * c->n_slots / unit;
+        want = (size_t)(c->plan_run_factor * std::sqrt(u) * unit / c->n_slots);
+    } else {
+        want = std::max<size_t>(1, ((size_t)8 << 20) / c->n_slots);
+    }
     c->run_passes = std::min<size_t>(c->max_batch, std::max(min_run, want));
 }
+
 int realloc_tile(gpuart_hip_ctx *c) {
     int r = gpuart_hip_flush(c);
     if (r) return r;
@@ -624,7 +641,7 @@ int realloc_tile(gpuart_hip_ctx *c) {
     // finishing their last, long rays with few lanes busy — shrinks relative to the useful work (SQ_INSTS_VALU per
     // ray falls by a quarter from 2M to 16M paths per launch at 1080p).
     size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, c->batch_paths / n));
-    if (n * B > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
+    if (n * B > 0x7ffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");  // two queues share one 32-bit index space in k_trace
     for (auto &l : c->lanes) {
         if (l.pathmem) { (void)hipFree(l.pathmem); l.pathmem = nullptr; }
         l.used = false;
@@ -677,12 +694,6 @@ int ensure_segment_counters(gpuart_hip_ctx *c, PassLane &l, uint32_t nseg) {
     if (l.pb.counters) { int r = drain(c); if (r) return r; (void)hipFree(l.pb.counters); l.pb.counters = nullptr; }
     HIP_TRY(hipMalloc(&l.pb.counters, 4 * ((size_t)nseg + 1) * sizeof(uint32_t)));
     l.counter_segments = nseg;
-    while (l.ev_shaded.size() < nseg) {
-        hipEvent_t e1, e2;
-        HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-        l.ev_shaded.push_back(e1); l.ev_shadowed.push_back(e2);
-    }
     return 0;
 }
 
@@ -696,9 +707,7 @@ int ensure_spill(gpuart_hip_ctx *c) {
     HIP_TRY(hipMalloc(&c->d_spill, bytes));
     for (auto &l : c->lanes) {
         if (l.spill_main) { (void)hipFree(l.spill_main); l.spill_main = nullptr; }
-        if (l.spill_shadow) { (void)hipFree(l.spill_shadow); l.spill_shadow = nullptr; }
         HIP_TRY(hipMalloc(&l.spill_main, bytes));
-        HIP_TRY(hipMalloc(&l.spill_shadow, bytes));
     }
     c->spill_levels = levels;
     return 0;
@@ -942,17 +951,15 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
-    c->overlap = (int)env_u32("GPUART_HIP_OVERLAP", 1, 0, 1);
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
     c->batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
-    c->plan_runs_target = env_u32("GPUART_HIP_PLAN_RUNS", 5, 1, 32);
+    c->plan_run_factor = env_u32("GPUART_HIP_PLAN_RUN_PERCENT", 75, 1, 1000) / 100.0;
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
     c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&l.shadow, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&l.ev_free, hipEventDisableTiming) != hipSuccess) {
             gpuart_hip_destroy(c);
@@ -975,14 +982,11 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &l : c->lanes) {
-        for (auto e : l.ev_shaded) (void)hipEventDestroy(e);
-        for (auto e : l.ev_shadowed) (void)hipEventDestroy(e);
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.ev_free) (void)hipEventDestroy(l.ev_free);
-        void *lp[] = {l.pathmem, l.spill_main, l.spill_shadow, l.pb.counters};
+        void *lp[] = {l.pathmem, l.spill_main, l.pb.counters};
         for (void *p : lp) if (p) (void)hipFree(p);
         if (l.main) (void)hipStreamDestroy(l.main);
-        if (l.shadow) (void)hipStreamDestroy(l.shadow);
     }
     void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1148,46 +1152,32 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots * b.batch / BLOCK));
+    int j_cur = 0;
     if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous pass has been accumulated
     if ((r = begin_timed(c, t, 0, l.main))) return r;
+    // one BVH-query launch: closest-hit queries of segment seg_c and / or Sun-shadow queries of segment seg_s
+    auto trace = [&](int seg_c, int seg_s) -> int {
+        TimedLaunch tt;
+        int rr;
+        if (detail && (rr = begin_timed(c, tt, 1, l.main))) return rr;
+        if (refwork) k_trace<true, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 0, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+        else if (flat_only) k_trace<false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+        else k_trace<false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+        if (detail && (rr = end_timed(c, tt, l.main))) return rr;
+        return 0;
+    };
     for (int j = 0; j < npaths; j++) {
-        int shadow_pending = -1;
+        j_cur = j;
         HIP_TRY(hipMemsetAsync(b.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
         k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seeds, j, npaths, b, l.passcolor);
+        if (nseg && (r = trace(0, -1))) return r;
         for (uint32_t seg = 0; seg < nseg; seg++) {
-            TimedLaunch tt;
-            if (detail && (r = begin_timed(c, tt, 1, l.main))) return r;
-            if (refwork) k_trace<false, false, true, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-            else if (flat_only) k_trace<false, false, false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-            else k_trace<false, false, false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-            if (detail && (r = end_timed(c, tt, l.main))) return r;
-            if (shadow_pending >= 0) {  // the previous segment's shadow pass updates pathColor, which shading reads
-                HIP_TRY(hipStreamWaitEvent(l.main, l.ev_shadowed[shadow_pending], 0));
-                shadow_pending = -1;
-            }
             if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
             else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
-            if (p->sunEnabled == 1) {
-                // The Sun-shadow queries of this segment run on the lane's second stream, beside the closest-hit
-                // queries of the next segment (independent data); the next shading kernel waits for them.
-                hipStream_t ss = c->overlap ? l.shadow : l.main;
-                uint4 *sspill = c->overlap ? l.spill_shadow : l.spill_main;
-                if (c->overlap) {
-                    HIP_TRY(hipEventRecord(l.ev_shaded[seg], l.main));
-                    HIP_TRY(hipStreamWaitEvent(ss, l.ev_shaded[seg], 0));
-                }
-                if (detail && (r = begin_timed(c, tt, 1, ss))) return r;
-                if (refwork) k_trace<true, false, true, GD_ALL_TYPES><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
-                else if (flat_only) k_trace<true, true, false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
-                else k_trace<true, true, false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, ss>>>(sc, c->frame, *p, b, (int)seg, j, npaths, l.passcolor, sspill, c->d_counters, c->tune);
-                if (detail && (r = end_timed(c, tt, ss))) return r;
-                if (c->overlap) {
-                    HIP_TRY(hipEventRecord(l.ev_shadowed[seg], ss));
-                    shadow_pending = (int)seg;
-                }
-            }
+            // the Sun-shadow queries of this segment travel with the closest-hit queries of the next one
+            const int next_c = seg + 1 < nseg ? (int)seg + 1 : -1, sh = p->sunEnabled == 1 ? (int)seg : -1;
+            if ((next_c >= 0 || sh >= 0) && (r = trace(next_c, sh))) return r;
         }
-        if (shadow_pending >= 0) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_shadowed[shadow_pending], 0));
         HIP_TRY(hipGetLastError());
     }
     if ((r = end_timed(c, t, l.main))) return r;

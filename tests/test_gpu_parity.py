@@ -587,7 +587,7 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan):
     {"GPUART_HIP_LANE_BUDGET_MB": "64", "GPUART_HIP_BATCH_MPATHS": "1"},
     {"GPUART_HIP_PASSES_IN_FLIGHT": "1", "GPUART_HIP_MAX_BATCH": "3", "GPUART_HIP_LEAN_KERNELS": "0"},
     {"GPUART_HIP_WAVES_PER_CU": "1", "GPUART_HIP_CHUNK": "16", "GPUART_HIP_REFILL_LANES": "1", "GPUART_HIP_LEAF_LANES": "64",
-     "GPUART_HIP_OVERLAP": "0", "GPUART_HIP_PLAN_RUNS": "32"},
+     "GPUART_HIP_PLAN_RUN_PERCENT": "10"},
 ])
 def test_scheduling_knobs_never_change_the_result(B, O, env, monkeypatch):
     """Memory budget, lanes in flight, run sizes, persistent-grid size, refill / leaf thresholds, kernel specialisation:
