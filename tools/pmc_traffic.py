@@ -17,8 +17,8 @@ def per_launch(d, counter):
             if row["Counter_Name"] != counter:
                 continue
             k = row["Kernel_Name"]
-            # fast-mode launches only: k_trace<SHADOW, ANY, COUNT=false>
-            if "k_trace<" in k and k.split("k_trace<")[1].split(">")[0].split(",")[2].strip() == "false":
+            # fast-mode launches only: k_trace<COUNT = false, TYPES>
+            if "k_trace<" in k and k.split("k_trace<")[1].split(">")[0].split(",")[0].strip() == "false":
                 key = "k_trace"
             elif "k_shade<false>" in k:
                 key = "k_shade"
