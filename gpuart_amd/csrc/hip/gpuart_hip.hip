@@ -233,19 +233,19 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             if (exhausted) break;
             continue;
         }
-        // ---- traverse until enough lanes have finished
+        // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
-            if (slot != SLOT_INVALID && t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
-            unsigned long long at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
-            unsigned long long descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
+            unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
+            unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
-                if (slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS)) {
+                if (t.state & 1) {
                     trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
                     if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                 }
-                descending = __ballot(slot != SLOT_INVALID && t.state == TRAV_DESCEND);
-                at_leaf = __ballot(slot != SLOT_INVALID && (t.state == TRAV_LEAF || t.state == TRAV_LEAF_TRIS));
+                descending = __ballot(t.state == TRAV_DESCEND);
+                at_leaf = __ballot((t.state & 1) != 0);
             }
             unsigned long long busy = descending | at_leaf;
             if (!busy) break;
