@@ -1,0 +1,126 @@
+// converter.h — host side of gpuart_hip_upload_bvh: validates the reference's canonical compiled tree (RGBA32F quads,
+// reference src/bvh.cpp:161-222) and re-lays it out as 64-byte two-children records + 48-byte primitive records
+// (DESIGN.md section 3). Host code only; included by gpuart_hip.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+
+namespace {
+
+using namespace gd;
+
+// ---- canonical tree -> device layout ---------------------------------------------------------------
+struct Converter {
+    const float *q;
+    size_t nq;
+    std::vector<float4> recs, prims;
+    size_t num_nodes = 0;
+    uint32_t type_mask = 0;
+    uint32_t max_depth = 0;
+    std::string err;
+
+    static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+    static float fbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+    /// Appends the device record of one canonical primitive payload (type + data quads).
+    static bool pack_prim(uint32_t type, const float *d, float4 rec[3]) {
+        float T = fbits(type);
+        switch (type) {
+        case P_SPHERE:
+            rec[0] = make_float4(d[0], d[1], d[2], T); rec[1] = make_float4(d[3], 0, 0, 0); rec[2] = make_float4(0, 0, 0, 0);
+            return true;
+        case P_DISC:
+            rec[0] = make_float4(d[0], d[1], d[2], T); rec[1] = make_float4(d[4], d[5], d[6], d[3]); rec[2] = make_float4(0, 0, 0, 0);
+            return true;
+        case P_TRIANGLE:
+            rec[0] = make_float4(d[0], d[1], d[2], T);
+            rec[1] = make_float4(d[4] - d[0], d[5] - d[1], d[6] - d[2], 0);   // edge1 = v1 - v0
+            rec[2] = make_float4(d[8] - d[0], d[9] - d[1], d[10] - d[2], 0);  // edge2 = v2 - v0
+            return true;
+        case P_CONE:
+            rec[0] = make_float4(d[0], d[1], d[2], T);
+            rec[1] = make_float4(d[8], d[9], d[10], d[11]);
+            rec[2] = make_float4(d[3], d[12], d[13], d[14]);
+            return true;
+        }
+        return false;
+    }
+
+    /// Result of converting one canonical node: its box and the ref its parent stores for it.
+    struct Child {
+        float bmin[3], bmax[3];
+        uint32_t ref;
+    };
+
+    /// A box that is inverted (min > max on some axis: e.g. a sphere with a negative radius, or the empty scene)
+    /// or holds a NaN can never be hit by the reference's comparisons. The device's box test assumes min <= max,
+    /// so such a box is replaced by a point box far outside anything a ray can reach (its entry parameter
+    /// would exceed the initial `closest` of 1e19, so it is never entered).
+    static void sanitize(Child &c) {
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok = ok && (c.bmin[k] <= c.bmax[k]);  // false for NaN too
+        if (!ok)
+            for (int k = 0; k < 3; k++) c.bmin[k] = c.bmax[k] = 3.0e+38f;
+    }
+
+    /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
+    /// interior lower child's record directly follows its parent's); leaves append their primitives.
+    bool node(size_t addr, uint32_t depth, Child &out) {
+        if (addr + 3 > nq) { err = "node address out of range"; return false; }
+        if (depth > 1024) { err = "tree deeper than 1024 levels"; return false; }
+        if (depth > max_depth) max_depth = depth;
+        num_nodes++;
+        const float *b = q + 4 * addr;
+        for (int k = 0; k < 3; k++) { out.bmin[k] = b[k]; out.bmax[k] = b[4 + k]; }
+        uint32_t flags = bits(b[8]);
+        if (flags & 0x80000000u) {
+            uint32_t n = flags & ~0xE0000000u;
+            uint32_t first = (uint32_t)(prims.size() / 3);
+            if (first >= 0x3ffffff0u) { err = "too many primitives"; return false; }
+            size_t a = addr + 3;
+            static const int LEN[4] = {1, 2, 3, 4};
+            bool all_tris = n >= 1 && n <= 2;
+            for (uint32_t i = 0; i < n; i++) {
+                if (a + 1 > nq) { err = "primitive header out of range"; return false; }
+                uint32_t type = bits(q[4 * a]);
+                if (type > 3) { err = "unknown primitive type"; return false; }
+                if (type != P_TRIANGLE) all_tris = false;
+                type_mask |= 1u << type;
+                if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
+                float4 rec[3];
+                pack_prim(type, q + 4 * (a + 1), rec);
+                if (i == 0) rec[0].w = fbits(type | (n << 2));  // the first primitive carries the leaf's count
+                prims.push_back(rec[0]); prims.push_back(rec[1]); prims.push_back(rec[2]);
+                a += 1 + LEN[type];
+            }
+            if (n == 0) {  // empty leaf (empty scene): one dummy record with count 0
+                prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
+            }
+            out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS : 0u) | first;
+            return true;
+        }
+        uint32_t lo = bits(b[9]), hi = bits(b[10]);
+        if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
+        if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
+        const size_t r = recs.size() / 4;
+        if (r >= 0x3ffffff0u) { err = "too many nodes"; return false; }
+        recs.resize(recs.size() + 4);
+        Child L, H;
+        if (!node(lo, depth + 1, L)) return false;
+        if (!node(hi, depth + 1, H)) return false;
+        sanitize(L); sanitize(H);
+        recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
+        recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
+        recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], 0);
+        recs[4 * r + 3] = make_float4(H.bmax[0], H.bmax[1], H.bmax[2], 0);
+        out.ref = (uint32_t)r;
+        return true;
+    }
+};
+
+}  // namespace

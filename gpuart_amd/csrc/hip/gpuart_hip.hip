@@ -1,4 +1,5 @@
-// gpuart_hip.hip — render kernels and the C-ABI launcher of libgpuart_hip.so (gfx950 only).
+// gpuart_hip.hip — context, scheduling and the C-ABI launcher of libgpuart_hip.so (gfx950 only); the kernels live in
+// kernels_pipeline.h / kernels_test.h, the tree re-layout in converter.h.
 // See include/gpuart_hip.h for the boundary and DESIGN.md for layout / kernel notes.
 #include <hip/hip_runtime.h>
 
@@ -14,470 +15,9 @@
 #include "device_shade.h"
 #include "gpuart_hip.h"
 
-using namespace gd;
-
-#define BLOCK 64          // one wavefront per workgroup
-#define SHADE_ROUNDS 8    // queue entries per lane a shading wave handles between two queue appends
-
-/// Scheduling knobs of the persistent BVH-query kernel (defaults chosen by tools/sweep.py on MI355X;
-/// overridable through GPUART_HIP_* environment variables for tuning runs; results never depend on them).
-struct TraceTuning {
-    uint32_t chunk;         ///< rays a wave takes from a queue per fetch
-    uint32_t refill_lanes;  ///< a wave goes back for new rays once this many lanes are idle
-    uint32_t leaf_lanes;    ///< primitive tests are issued once this many lanes wait at a leaf
-};
-
-// =================================================================================================
-// Kernels
-// =================================================================================================
-namespace {
-
-/// Per-path state of the wavefront pipeline, one slot per pixel of the tile in 8x8-tile-major order
-/// (slot s: tile s/64, pixel s%64 inside it), all arrays SoA and 16-byte aligned.
-struct PathBuffers {
-    float4 *ray_o, *ray_d;   ///< ray of the current / next segment
-    uint2 *hit;              ///< closest-hit result of the current segment: (bits(t), primitive index)
-    float4 *cw;              ///< colorWeight
-    float4 *pc;              ///< pathColor
-    float4 *sun;             ///< pending Sun term (xyz), w = bits(1: the path ends after its shadow query)
-    float4 *color;           ///< colour of the earlier paths of this pass (NumPathsPerPixel > 1)
-    uint32_t *queue[2];      ///< slots that trace segment s (ping-pong)
-    uint32_t *shadow_queue;  ///< slots with a pending Sun shadow query
-    uint32_t *counters;      ///< per segment s: [4s] rays, [4s+1] fetch cursor, [4s+2] shadow rays, [4s+3] fetch cursor
-    uint32_t n_slots;        ///< path slots per pass (pixels of the tile, 8x8-tile padded)
-    uint32_t batch;          ///< passes processed together: slot s belongs to pass s / n_slots, pixel slot s % n_slots
-    uint32_t tile_pixels;    ///< stride between the passes' colour planes in `passcolor`
-};
-
-#define MAX_BATCH 64
-/// RandSeed of every pass of a pipeline run (slot = pass x pixel; up to 16M paths or MAX_BATCH passes per run).
-struct SeedBatch {
-    float4 seed[MAX_BATCH];
-};
-#define SLOT_INVALID 0xffffffffu
-
-GD_FN int lane_id() { return threadIdx.x & 63; }
-
-GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned long long *g) {
-    // one atomic per counter per wavefront
-    uint32_t v[7] = {wc.rays, wc.nodes, wc.prims[0], wc.prims[1], wc.prims[2], wc.prims[3], segments};
-    for (int k = 0; k < 7; k++) {
-        unsigned long long s = v[k];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane_id() == 0 && s) atomicAdd(&g[k], s);
-    }
-}
-
-/// slot -> pixel of the tile; false for the padding slots of ragged edge tiles.
-GD_FN bool slot_pixel(const Frame &f, uint32_t slot, uint32_t &lx, uint32_t &ly) {
-    uint32_t tiles_x = (f.tw + 7) / 8;
-    uint32_t t = slot >> 6, w = slot & 63;
-    lx = (t % tiles_x) * 8 + (w & 7);
-    ly = (t / tiles_x) * 8 + (w >> 3);
-    return lx < f.tw && ly < f.th;
-}
-
-GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes) {
-    TravStack st;
-    st.ring_a = ring_a + lane_id();
-    st.ring_b = ring_b + lane_id();
-    st.ring_stride = BLOCK;
-    st.spill = spill + (size_t)blockIdx.x * BLOCK + lane_id();
-    st.spill_stride = total_lanes;
-    st.reset();
-    return st;
-}
-
-/// Wave-aggregated append: lanes with `pred` get consecutive positions of `queue` (one atomic per wave).
-GD_FN void queue_push(uint32_t *queue, uint32_t *counter, bool pred, uint32_t value) {
-    unsigned long long m = __ballot(pred);
-    if (!m) return;
-    uint32_t base = 0;
-    int leader = __ffsll((long long)m) - 1;
-    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1))] = value;
-}
-
-/// Adds a finished path's colour to its pixel's colour of this pass (path_tracing.glsl:252: color += pathColor for
-/// every path of the pass). The last path stores the pass colour in `passcolor` (tile row-major); k_accumulate then
-/// performs path_tracing.glsl:255, accum = PrevRadiance + color, in pass order.
-GD_FN void path_commit(const Frame &f, const PathBuffers &b, float4 *passcolor, uint32_t slot, int j, int npaths, F3 value) {
-    F3 c = (j == 0) ? f3(0.0f + value.x, 0.0f + value.y, 0.0f + value.z) : xyz(b.color[slot]) + value;
-    if (j == npaths - 1) {
-        uint32_t lx, ly;
-        slot_pixel(f, slot % b.n_slots, lx, ly);
-        passcolor[(size_t)(slot / b.n_slots) * b.tile_pixels + (size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 0);
-    } else
-        b.color[slot] = make_float4(c.x, c.y, c.z, 0);
-}
-
-/// path_tracing.glsl:255 for one finished pass: accum = PrevRadiance + color. Launched in pass order on the
-/// context's primary stream, so float additions happen in the reference's order whatever the overlap of passes.
-__global__ void k_accumulate(float4 *__restrict__ accum, const float4 *__restrict__ passcolor, size_t n, uint32_t batch) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        float4 a = accum[i];
-        for (uint32_t k = 0; k < batch; k++) {  // the passes of a batch, oldest first
-            float4 c = passcolor[(size_t)k * n + i];
-            a = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w);
-        }
-        accum[i] = a;
-    }
-}
-
-// ---- wavefront stage 0: first ray of path j of every pixel (path_tracing.glsl:141-175) ---------------
-__global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBatch seeds, int j, int npaths, PathBuffers b,
-                                               float4 *accum) {
-    const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
-    const uint32_t total = b.n_slots * b.batch;
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < total; slot += gridDim.x * BLOCK) {
-        uint32_t lx, ly;
-        bool valid = slot_pixel(f, slot % b.n_slots, lx, ly);
-        const float4 seed = seeds.seed[slot / b.n_slots];
-        uint32_t q = SLOT_INVALID;
-        if (valid) {
-            F3 rs0, rd0, rs, rd;
-            camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
-            if (no_segments) {  // the GLSL loop body never runs: i == 0 and no user-sphere hit
-                path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, 0, false, false, f3(0, 0, 0)));
-            } else {
-                path_begin(P, seed, j, rs0, rd0, rs, rd);
-                b.ray_o[slot] = make_float4(rs.x, rs.y, rs.z, 0);
-                b.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, 0);
-                b.cw[slot] = make_float4(1, 1, 1, 0);
-                b.pc[slot] = make_float4(0, 0, 0, 0);
-                q = slot;
-            }
-        }
-        b.queue[0][slot] = q;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.counters[0] = no_segments ? 0u : total;
-}
-
-// ---- wavefront stage 1/3: BVH queries, persistent waves with lane refill ----------------------------------
-// One launch serves two queues at once: the closest-hit queries of segment `seg_c` (slots of queue[seg_c&1]; result ->
-// hit[slot]) and the Sun-shadow queries of segment `seg_s` (slots of shadow_queue; they apply the Sun term and, for
-// paths that end with that segment, commit the path) — after shading segment s both the shadow queries of s and the
-// closest-hit queries of s+1 are ready and touch disjoint data. Either may be absent (-1). The long closest-hit rays
-// come first in the combined index space, the short shadow rays (they stop at the first accepted hit when
-// `any_shadow`) fill the end of the launch.
-// A lane that finishes its ray takes the next one from the queue (wave-local chunk, one atomic per chunk), so all
-// 64 lanes keep traversing; box tests and leaf tests are issued as separate wave-wide phases (leaf code waits until
-// LEAF_LANES lanes need it).
-#define GD_FLAT_TYPES ((1 << gd::P_DISC) | (1 << gd::P_TRIANGLE))
-#ifndef GD_TRACE_WAVES
-#define GD_TRACE_WAVES 5  // waves per SIMD the register allocation must allow (<= 96 VGPRs)
-#endif
-#ifndef GD_TRACE_WAVES_LEAN
-#define GD_TRACE_WAVES_LEAN 6  // the kernels without cone / sphere code fit 6 waves per SIMD (<= 80 VGPRs)
-#endif
-template <bool COUNT, int TYPES>
-__global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES_LEAN : GD_TRACE_WAVES)
-k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s, int any_shadow, int j, int npaths, float4 *accum,
-        uint4 *spill, unsigned long long *gcounters, TraceTuning tune) {
-    __shared__ uint2 ring_a[GD_RING * BLOCK];
-    __shared__ float ring_b[GD_RING * BLOCK];
-    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    const uint32_t *queue_c = b.queue[seg_c & 1];
-    const uint32_t n_c = seg_c >= 0 ? b.counters[4 * seg_c] : 0u;
-    const uint32_t n = n_c + (seg_s >= 0 ? b.counters[4 * seg_s + 2] : 0u);
-    uint32_t *cursor = &b.counters[seg_c >= 0 ? 4 * seg_c + 1 : 4 * seg_s + 3];
-    const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
-
-    // The first chunk of every wave is static (chunk index = workgroup index); later chunks come from the
-    // shared cursor, which therefore starts behind the static ones. No atomic at all for small queues.
-    const uint32_t static_end = gridDim.x * tune.chunk;
-    uint32_t chunk_next = min(blockIdx.x * tune.chunk, n), chunk_end = min((blockIdx.x + 1) * tune.chunk, n);  // wave-uniform
-    bool exhausted = false;                                                                                   // wave-uniform
-    uint32_t slot = SLOT_INVALID;
-    bool shadow = false;                    // this lane's ray is a Sun-shadow query
-    F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0);  // the ray (two F3 locals: a long-lived Ray aggregate ends up in scratch)
-    F3 rdiv = f3(1, 1, 1);
-    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
-
-    for (;;) {
-        // ---- refill idle lanes from the queue
-        unsigned long long idle = __ballot(slot == SLOT_INVALID);
-        while (idle && !exhausted) {
-            if (chunk_next == chunk_end) {
-                if (static_end >= n) { exhausted = true; break; }
-                uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(cursor, tune.chunk);
-                base = __shfl(base, 0, 64) + static_end;
-                if (base >= n) { exhausted = true; break; }
-                chunk_next = base;
-                chunk_end = min(base + tune.chunk, n);
-            }
-            uint32_t want = (uint32_t)__popcll(idle), take = min(want, chunk_end - chunk_next);
-            uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1));
-            if (slot == SLOT_INVALID && rank < take) {
-                const uint32_t i = chunk_next + rank;
-                const bool sh = i >= n_c;
-                uint32_t s = sh ? b.shadow_queue[i - n_c] : queue_c[i];
-                if (s != SLOT_INVALID) {
-                    slot = s;
-                    shadow = sh;
-                    ro = xyz(b.ray_o[s]);
-                    rd = sh ? sun : xyz(b.ray_d[s]);
-                    rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                    trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
-                }
-            }
-            chunk_next += take;
-            idle = __ballot(slot == SLOT_INVALID);
-            if (take == want) break;
-        }
-        if (__ballot(slot != SLOT_INVALID) == 0) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
-        for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
-            unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
-            unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
-            if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
-                if (t.state & 1) {
-                    trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
-                    // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
-                    if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
-                }
-                descending = __ballot(t.state == TRAV_DESCEND);
-                at_leaf = __ballot((t.state & 1) != 0);
-            }
-            unsigned long long busy = descending | at_leaf;
-            if (!busy) break;
-            if (!exhausted && 64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
-        }
-        // ---- retire finished rays
-        if (slot != SLOT_INVALID && t.state == TRAV_DONE) {
-            if (!shadow) {
-                b.hit[slot] = make_uint2(__float_as_uint(t.closest), t.hit_prim);
-            } else {
-                float4 term = b.sun[slot];
-                F3 pathColor = xyz(b.pc[slot]);
-                if (sun_visible(P, ro, sun, t.hit_prim)) pathColor = pathColor + xyz(term);
-                if (__float_as_uint(term.w) & 1u) path_commit(f, b, accum, slot, j, npaths, pathColor);
-                else b.pc[slot] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
-            }
-            slot = SLOT_INVALID;
-        }
-    }
-    if (COUNT) flush_counters(wc, 0, gcounters);
-}
-
-// ---- wavefront stage 2: shade segment `seg` of every path in queue[seg&1] (path_tracing.glsl:182-233) ---
-template <bool REFWORK>
-__global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int seg,
-                                                 int j, int npaths, float4 *accum, unsigned long long *gcounters) {
-    // Survivors are appended to the next queues through a per-wave staging list in LDS that is flushed with
-    // ONE atomic per SHADE_ROUNDS*64 processed paths: a single atomic word sustains only ~90 appends/us on
-    // MI355X, and one append per wave per 64 paths made this kernel atomic-bound.
-    __shared__ uint32_t stage_next[SHADE_ROUNDS * BLOCK], stage_shadow[SHADE_ROUNDS * BLOCK];
-    const uint32_t n = b.counters[4 * seg];
-    const uint32_t *queue = b.queue[seg & 1];
-    uint32_t *next_queue = b.queue[(seg + 1) & 1];
-    uint32_t segments = 0;
-    const uint32_t span = SHADE_ROUNDS * BLOCK;                 // consecutive queue entries one wave handles at a time
-    const uint32_t spans = (n + span - 1) / span;
-    for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
-      uint32_t n_next = 0, n_shadow = 0;                        // wave-uniform fill of the staging lists
-      for (uint32_t k = 0; k < SHADE_ROUNDS; k++) {
-        uint32_t e = sp * span + k * BLOCK + threadIdx.x;
-        uint32_t slot = e < n ? queue[e] : SLOT_INVALID;
-        bool go_on = false, shadow = false;
-        if (slot != SLOT_INVALID) {
-            Ray r; r.o = xyz(b.ray_o[slot]); r.d = xyz(b.ray_d[slot]);
-            uint2 h = b.hit[slot];
-            F3 cw = xyz(b.cw[slot]), pathColor = xyz(b.pc[slot]);
-            F3 rstart = r.o, rdir = r.d;
-            segments++;
-            const float4 seed = seeds.seed[slot / b.n_slots];
-            ShadeResult s = path_shade(sc, P, seed, seg, r, __uint_as_float(h.x), h.y, rstart, rdir, cw, pathColor);
-            if (s.broke) {
-                uint32_t lx, ly; F3 rs0, rd0;
-                slot_pixel(f, slot % b.n_slots, lx, ly);
-                camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
-                path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, seg, s.ush, s.specular, pathColor));
-            } else {
-                go_on = s.next == PATH_CONTINUES;
-                shadow = s.want_shadow && (REFWORK || s.sun_matters);
-                if (shadow)
-                    b.sun[slot] = make_float4(s.sun_term.x, s.sun_term.y, s.sun_term.z, __uint_as_float(go_on ? 0u : 1u));
-                if (go_on || shadow) b.ray_o[slot] = make_float4(rstart.x, rstart.y, rstart.z, 0);
-                if (go_on) {
-                    b.ray_d[slot] = make_float4(rdir.x, rdir.y, rdir.z, 0);
-                    b.cw[slot] = make_float4(cw.x, cw.y, cw.z, 0);
-                }
-                if (go_on || shadow) b.pc[slot] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
-                if (!go_on && !shadow) path_commit(f, b, accum, slot, j, npaths, pathColor);  // i >= 1: no special case
-            }
-        }
-        unsigned long long m1 = __ballot(go_on), m2 = __ballot(shadow);
-        unsigned long long below = (1ull << lane_id()) - 1;
-        if (go_on) stage_next[n_next + (uint32_t)__popcll(m1 & below)] = slot;
-        if (shadow) stage_shadow[n_shadow + (uint32_t)__popcll(m2 & below)] = slot;
-        n_next += (uint32_t)__popcll(m1);
-        n_shadow += (uint32_t)__popcll(m2);
-      }
-      // flush: one atomic per list, then a coalesced copy
-      __syncthreads();
-      uint32_t base1 = 0, base2 = 0;
-      if (lane_id() == 0) {
-          if (n_next) base1 = atomicAdd(&b.counters[4 * (seg + 1)], n_next);
-          if (n_shadow) base2 = atomicAdd(&b.counters[4 * seg + 2], n_shadow);
-      }
-      base1 = __shfl(base1, 0, 64);
-      base2 = __shfl(base2, 0, 64);
-      for (uint32_t i = threadIdx.x; i < n_next; i += BLOCK) next_queue[base1 + i] = stage_next[i];
-      for (uint32_t i = threadIdx.x; i < n_shadow; i += BLOCK) b.shadow_queue[base2 + i] = stage_shadow[i];
-      __syncthreads();
-    }
-    if (REFWORK) {
-        WorkCounters z = {0, 0, {0, 0, 0, 0}};
-        flush_counters(z, segments, gcounters);
-    }
-}
-
-// ---- megakernels: one thread per pixel, persistent grid over 8x8 tiles -------------------------------------
-template <bool REFWORK>
-__global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_params P, uint32_t n_slots, float4 *__restrict__ out,
-                                                  uint4 *spill, unsigned long long *counters) {
-    __shared__ uint2 ring_a[GD_RING * BLOCK];
-    __shared__ float ring_b[GD_RING * BLOCK];
-    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
-        uint32_t lx, ly;
-        if (!slot_pixel(f, slot, lx, ly)) continue;
-        F3 rs, rd;
-        camera_ray(f, f.x0 + lx, frame_y(f, ly), rs, rd);
-        F3 c = direct_lighting_pixel<REFWORK>(sc, P, rs, rd, st, &wc);
-        out[(size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 1.0f);
-    }
-    if (REFWORK) flush_counters(wc, 0, counters);
-}
-
-template <bool REFWORK>
-__global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_params P, float4 seed, int npaths, uint32_t n_slots,
-                                                   float4 *__restrict__ accum, uint4 *spill, unsigned long long *counters) {
-    __shared__ uint2 ring_a[GD_RING * BLOCK];
-    __shared__ float ring_b[GD_RING * BLOCK];
-    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
-    uint32_t segments = 0;
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
-        uint32_t lx, ly;
-        if (!slot_pixel(f, slot, lx, ly)) continue;
-        F3 rs, rd;
-        camera_ray(f, f.x0 + lx, frame_y(f, ly), rs, rd);
-        F3 c = path_tracing_pixel<REFWORK>(sc, P, seed, npaths, rs, rd, st, &wc, segments);
-        size_t idx = (size_t)ly * f.tw + lx;
-        float4 prev = accum[idx];
-        accum[idx] = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w);
-    }
-    if (REFWORK) flush_counters(wc, segments, counters);
-}
-
-__global__ void k_scale_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n, float divide_by) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        float4 v = src[i];
-        dst[i] = make_float4(v.x / divide_by, v.y / divide_by, v.z / divide_by, v.w);
-    }
-}
-
-// ---- test-hook kernels ---------------------------------------------------------------------------
-__global__ void k_test_random(const float4 *in, int n, float4 *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 v = in[i];
-    out[i] = make_float4(random1(v.x), random2(v.x, v.y), random3(f3(v.x, v.y, v.z)), random4(v));
-}
-__global__ void k_test_math(const float4 *in, int n, float4 *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s, c;
-    sincos_lp(in[i].x, s, c);
-    out[i] = make_float4(s, c, pow_lp(in[i].y, 16.0f), sqrtf(in[i].y));
-}
-__global__ void k_test_hemisphere(const float4 *v, const float4 *ri, int n, float4 *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    F3 r = random_hemisphere_direction(xyz(v[i]), xyz(ri[i]));
-    out[i] = make_float4(r.x, r.y, r.z, 0);
-}
-__global__ void k_test_inside_cone(const float4 *v, const float4 *nrm, const float4 *ri, float ha, int n, float4 *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    F3 r = random_direction_inside_cone(xyz(v[i]), xyz(nrm[i]), ha, xyz(ri[i]));
-    out[i] = make_float4(r.x, r.y, r.z, 0);
-}
-struct Float4Arg { float v[4]; };
-__global__ void k_test_sky(const float4 *dir, Float4Arg sda, int n, float4 *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    F3 r = sky_color(xyz(dir[i]), sda.v);
-    out[i] = make_float4(r.x, r.y, r.z, 0);
-}
-/// recs: n device-layout primitive records (3 quads each)
-__global__ void k_test_intersect(const float4 *rs, const float4 *rd, const float4 *recs, int n, float4 *o0, float4 *o1) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
-    float pos; F3 p = f3(0, 0, 0), nn = f3(0, 0, 0); int t;
-    prim_hit(r, recs[3 * i], recs[3 * i + 1], recs[3 * i + 2], pos, p, nn, t);
-    if (pos > 0) { o0[i] = make_float4(pos, p.x, p.y, p.z); o1[i] = make_float4(nn.x, nn.y, nn.z, 0); }
-    else { o0[i] = make_float4(pos, 0, 0, 0); o1[i] = make_float4(0, 0, 0, 0); }
-}
-__global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bmin, const float4 *bmax, int n, float4 *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
-    float pos;
-    bool h = aabb_entry(r, f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z), xyz(bmin[i]), xyz(bmax[i]), pos);
-    out[i] = make_float4(h ? 1.0f : 0.0f, h ? pos : 0.0f, 0, 0);
-}
-template <bool ANY>
-__global__ void __launch_bounds__(BLOCK) k_test_traverse(Scene sc, const float4 *rs, const float4 *rd, Float4Arg us, int n,
-                                                         float4 *o0, float4 *o1, uint4 *spill) {
-    __shared__ uint2 ring_a[GD_RING * BLOCK];
-    __shared__ float ring_b[GD_RING * BLOCK];
-    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
-        float closest; uint32_t prim;
-        traverse<ANY, false>(sc, r, st, closest, prim, nullptr);
-        if (ANY) {
-            o0[i] = make_float4(prim != GD_NO_PRIM ? 1.0f : 0.0f, 0, 0, 0);
-            o1[i] = make_float4(0, 0, 0, 0);
-            continue;
-        }
-        Surface h; h.p = f3(0, 0, 0); h.n = f3(0, 0, 0);
-        bool ush;
-        resolve_hit(sc, r, closest, prim, us.v, h, ush);
-        if (h.ptype >= 0) {
-            o0[i] = make_float4(h.pos, h.p.x, h.p.y, h.p.z);
-            o1[i] = make_float4(h.n.x, h.n.y, h.n.z, (float)h.ptype + (ush ? 0.5f : 0.0f));
-        } else {
-            o0[i] = make_float4(-1, 0, 0, 0);
-            o1[i] = make_float4(0, 0, 0, -1);
-        }
-    }
-}
-__global__ void k_test_cam_rays(Frame f, float4 *rstart, float4 *rdir) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= f.tw * f.th) return;
-    uint32_t lx = i % f.tw, ly = i / f.tw;
-    F3 s, d;
-    camera_ray(f, f.x0 + lx, frame_y(f, ly), s, d);
-    rstart[i] = make_float4(s.x, s.y, s.z, 0);
-    rdir[i] = make_float4(d.x, d.y, d.z, 0);
-}
-
-}  // namespace
+#include "kernels_pipeline.h"
+#include "kernels_test.h"
+#include "converter.h"
 
 // =================================================================================================
 // Host side: context, upload, launches
@@ -763,115 +303,6 @@ int end_timed(gpuart_hip_ctx *c, TimedLaunch &t, hipStream_t stream = nullptr) {
     c->pending.push_back(t);
     return 0;
 }
-
-// ---- canonical tree -> device layout ---------------------------------------------------------------
-struct Converter {
-    const float *q;
-    size_t nq;
-    std::vector<float4> recs, prims;
-    size_t num_nodes = 0;
-    uint32_t type_mask = 0;
-    uint32_t max_depth = 0;
-    std::string err;
-
-    static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-    static float fbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-
-    /// Appends the device record of one canonical primitive payload (type + data quads).
-    static bool pack_prim(uint32_t type, const float *d, float4 rec[3]) {
-        float T = fbits(type);
-        switch (type) {
-        case P_SPHERE:
-            rec[0] = make_float4(d[0], d[1], d[2], T); rec[1] = make_float4(d[3], 0, 0, 0); rec[2] = make_float4(0, 0, 0, 0);
-            return true;
-        case P_DISC:
-            rec[0] = make_float4(d[0], d[1], d[2], T); rec[1] = make_float4(d[4], d[5], d[6], d[3]); rec[2] = make_float4(0, 0, 0, 0);
-            return true;
-        case P_TRIANGLE:
-            rec[0] = make_float4(d[0], d[1], d[2], T);
-            rec[1] = make_float4(d[4] - d[0], d[5] - d[1], d[6] - d[2], 0);   // edge1 = v1 - v0
-            rec[2] = make_float4(d[8] - d[0], d[9] - d[1], d[10] - d[2], 0);  // edge2 = v2 - v0
-            return true;
-        case P_CONE:
-            rec[0] = make_float4(d[0], d[1], d[2], T);
-            rec[1] = make_float4(d[8], d[9], d[10], d[11]);
-            rec[2] = make_float4(d[3], d[12], d[13], d[14]);
-            return true;
-        }
-        return false;
-    }
-
-    /// Result of converting one canonical node: its box and the ref its parent stores for it.
-    struct Child {
-        float bmin[3], bmax[3];
-        uint32_t ref;
-    };
-
-    /// A box that is inverted (min > max on some axis: e.g. a sphere with a negative radius, or the empty scene)
-    /// or holds a NaN can never be hit by the reference's comparisons. The device's box test assumes min <= max,
-    /// so such a box is replaced by a point box far outside anything a ray can reach (its entry parameter
-    /// would exceed the initial `closest` of 1e19, so it is never entered).
-    static void sanitize(Child &c) {
-        bool ok = true;
-        for (int k = 0; k < 3; k++) ok = ok && (c.bmin[k] <= c.bmax[k]);  // false for NaN too
-        if (!ok)
-            for (int k = 0; k < 3; k++) c.bmin[k] = c.bmax[k] = 3.0e+38f;
-    }
-
-    /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
-    /// interior lower child's record directly follows its parent's); leaves append their primitives.
-    bool node(size_t addr, uint32_t depth, Child &out) {
-        if (addr + 3 > nq) { err = "node address out of range"; return false; }
-        if (depth > 1024) { err = "tree deeper than 1024 levels"; return false; }
-        if (depth > max_depth) max_depth = depth;
-        num_nodes++;
-        const float *b = q + 4 * addr;
-        for (int k = 0; k < 3; k++) { out.bmin[k] = b[k]; out.bmax[k] = b[4 + k]; }
-        uint32_t flags = bits(b[8]);
-        if (flags & 0x80000000u) {
-            uint32_t n = flags & ~0xE0000000u;
-            uint32_t first = (uint32_t)(prims.size() / 3);
-            if (first >= 0x3ffffff0u) { err = "too many primitives"; return false; }
-            size_t a = addr + 3;
-            static const int LEN[4] = {1, 2, 3, 4};
-            bool all_tris = n >= 1 && n <= 2;
-            for (uint32_t i = 0; i < n; i++) {
-                if (a + 1 > nq) { err = "primitive header out of range"; return false; }
-                uint32_t type = bits(q[4 * a]);
-                if (type > 3) { err = "unknown primitive type"; return false; }
-                if (type != P_TRIANGLE) all_tris = false;
-                type_mask |= 1u << type;
-                if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
-                float4 rec[3];
-                pack_prim(type, q + 4 * (a + 1), rec);
-                if (i == 0) rec[0].w = fbits(type | (n << 2));  // the first primitive carries the leaf's count
-                prims.push_back(rec[0]); prims.push_back(rec[1]); prims.push_back(rec[2]);
-                a += 1 + LEN[type];
-            }
-            if (n == 0) {  // empty leaf (empty scene): one dummy record with count 0
-                prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
-            }
-            out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS : 0u) | first;
-            return true;
-        }
-        uint32_t lo = bits(b[9]), hi = bits(b[10]);
-        if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
-        if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
-        const size_t r = recs.size() / 4;
-        if (r >= 0x3ffffff0u) { err = "too many nodes"; return false; }
-        recs.resize(recs.size() + 4);
-        Child L, H;
-        if (!node(lo, depth + 1, L)) return false;
-        if (!node(hi, depth + 1, H)) return false;
-        sanitize(L); sanitize(H);
-        recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
-        recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
-        recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], 0);
-        recs[4 * r + 3] = make_float4(H.bmax[0], H.bmax[1], H.bmax[2], 0);
-        out.ref = (uint32_t)r;
-        return true;
-    }
-};
 
 template <class T>
 int upload_vec(gpuart_hip_ctx *c, T *&dst, const std::vector<T> &v) {
