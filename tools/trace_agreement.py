@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Cross-check of bench.py's HIP-event timing against rocprofv3: the average duration of the fast-mode k_trace launches
+of the timed region (the last `launches` ones of the kernel trace) beside `roofline.kernel_avg_ms` of the bench line the
+same process printed.   tools/trace_agreement.py <x_kernel_trace.csv> <bench stdout of that run>"""
+import csv
+import json
+import sys
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"]
+    if "k_trace<" in k and k.split("k_trace<")[1].split(">")[0].split(",")[0].strip() == "false":
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+rows.sort()
+line = [l for l in open(sys.argv[2]).read().split("\n") if l.startswith("{")][-1]
+d = json.loads(line)
+n = d["roofline"]["launches"]
+sel = rows[-n:]
+avg = sum(e - s for s, e in sel) / len(sel) / 1e6
+print("command: python3 bench.py --steps %d --warmup %d --no-cpu-baseline (under rocprofv3 --kernel-trace --stats)" % (d["steps"], d["warmup"]))
+print("k_trace launches in the timed region: %d" % n)
+print("rocprofv3 kernel trace, average duration of those launches: %.4f ms" % avg)
+print("bench.py HIP events (roofline.kernel_avg_ms):                %.4f ms" % d["roofline"]["kernel_avg_ms"])
+print("ratio: %.3f" % (avg / d["roofline"]["kernel_avg_ms"]))
+print("bench line of the profiled run: value %.1f %s, ms_per_step %.4f, roofline.achieved %.1f GB/s, frac %.3f"
+      % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["frac"]))
