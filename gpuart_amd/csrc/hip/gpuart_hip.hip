@@ -92,7 +92,7 @@ struct gpuart_hip_ctx {
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
-    TraceTuning tune{128, 16, 16};
+    TraceTuning tune{128, 16, 16, 3};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
     uint32_t max_batch = 1;        ///< most passes one run of the pipeline may hold (batch_paths / tile slots, <= MAX_BATCH)
     uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
@@ -381,6 +381,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 128, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
+    c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);

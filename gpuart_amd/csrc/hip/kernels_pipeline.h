@@ -17,7 +17,8 @@ using namespace gd;
 struct TraceTuning {
     uint32_t chunk;         ///< rays a wave takes from a queue per fetch
     uint32_t refill_lanes;  ///< a wave goes back for new rays once this many lanes are idle
-    uint32_t leaf_lanes;    ///< primitive tests are issued once this many lanes wait at a leaf
+    uint32_t leaf_lanes;    ///< primitive tests are issued once this many lanes wait at a leaf ...
+    uint32_t leaf_share;    ///< ... or 1/leaf_share of the lanes that still hold a ray
 };
 
 // =================================================================================================
@@ -231,7 +232,10 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
-            if (at_leaf && ((uint32_t)__popcll(at_leaf) >= tune.leaf_lanes || !descending)) {
+            // leaves are tested once 1/leaf_share of the lanes that still have a ray wait at one (at most leaf_lanes):
+            // a wave that is draining its last rays must not hold leaves back for a quorum it can no longer reach
+            const uint32_t waiting = (uint32_t)__popcll(at_leaf);
+            if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
                     trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
