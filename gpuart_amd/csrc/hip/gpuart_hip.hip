@@ -92,6 +92,7 @@ struct gpuart_hip_ctx {
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
+    uint32_t shade_waves = 4096;   ///< grid of the streaming kernels (k_gen, k_shade): latency-bound, so more waves than k_trace
     TraceTuning tune{128, 16, 16, 3};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
     uint32_t max_batch = 1;        ///< most passes one run of the pipeline may hold (batch_paths / tile slots, <= MAX_BATCH)
@@ -378,6 +379,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     };
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 8, 1, 32);  // persistent grids of one-wave workgroups
+    c->shade_waves = c->num_cus * env_u32("GPUART_HIP_SHADE_WAVES_PER_CU", 24, 1, 64);
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 128, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
@@ -583,7 +585,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
-    const dim3 sgrid(std::min<uint32_t>(c->grid_waves, b.n_slots * b.batch / BLOCK));
+    const dim3 sgrid(std::min<uint32_t>(c->shade_waves, b.n_slots * b.batch / BLOCK));  // k_gen / k_shade: grid-stride loops
     int j_cur = 0;
     if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous pass has been accumulated
     if ((r = begin_timed(c, t, 0, l.main))) return r;
