@@ -124,6 +124,11 @@ def main():
     full = torch.empty((H, W, 4), dtype=torch.float32, device=xdev) if (dist is not None and rank == 0) else None
     run_passes(Wm)
     be.finish()
+    if dist is not None:
+        # warm the exchange path too: the first point-to-point transfer between two ranks sets up their channel
+        be.export(1, gather_buf.data_ptr(), float(max(1, Wm)))
+        be.finish()
+        sharding.gather_interleaved(dist, gather_buf.to(xdev), rank, world, H, full)
     r.set_seed(5489)
     be.set_timing(2)
     be.kernel_time(0, reset=True)

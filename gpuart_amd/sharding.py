@@ -58,20 +58,28 @@ def interleaved_rows(rank, world, height, band=8):
 
 
 def gather_interleaved(dist, local, rank, world, height, full=None, root=0, band=8):
-    """Gathers interleaved row bands (local: (local_rows, W, C) tensor) into `full` (height, W, C) on root."""
+    """Gathers interleaved row bands (local: (local_rows, W, C) tensor) into `full` (height, W, C) on root.
+    Point-to-point: the root posts all receives at once (every peer has its own xGMI link to the root), peers send."""
     import torch
     if rank == root:
+        bufs, ops = {}, []
         for src in range(world):
             _, n, _, _, rows = interleaved_rows(src, world, height, band)
             if n == 0:
                 continue
             if src == root:
-                buf = local
+                bufs[src] = (local, rows)
             else:
                 buf = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-                dist.recv(buf, src=src)
+                bufs[src] = (buf, rows)
+                ops.append(dist.P2POp(dist.irecv, buf, src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for src, (buf, rows) in bufs.items():
             full[torch.as_tensor(rows, device=full.device)] = buf
         return full
     if local.shape[0]:
-        dist.send(local.contiguous(), dst=root)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), root)]):
+            req.wait()
     return None
