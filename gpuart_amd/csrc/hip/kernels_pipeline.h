@@ -26,8 +26,8 @@ struct TraceTuning {
 // =================================================================================================
 namespace {
 
-/// Per-path state of the wavefront pipeline, one slot per pixel of the tile in 8x8-tile-major order
-/// (slot s: tile s/64, pixel s%64 inside it), all arrays SoA and 16-byte aligned.
+/// Per-path state of one run of the wavefront pipeline: `batch` passes x `n_slots` pixel slots (pixel slot p: 8x8 tile
+/// p/64 of the tile in row-major tile order, pixel p%64 inside it), all arrays SoA and 16-byte aligned.
 struct PathBuffers {
     float4 *ray_o, *ray_d;   ///< ray of the current / next segment
     uint2 *hit;              ///< closest-hit result of the current segment: (bits(t), primitive index)
@@ -37,7 +37,8 @@ struct PathBuffers {
     float4 *color;           ///< colour of the earlier paths of this pass (NumPathsPerPixel > 1)
     uint32_t *queue[2];      ///< slots that trace segment s (ping-pong)
     uint32_t *shadow_queue;  ///< slots with a pending Sun shadow query
-    uint32_t *counters;      ///< per segment s: [4s] rays, [4s+1] fetch cursor, [4s+2] shadow rays, [4s+3] fetch cursor
+    uint32_t *counters;      ///< per segment s: [4s] closest-hit rays, [4s+1] k_trace's fetch cursor (for the launch whose
+                             ///< closest part is s), [4s+2] shadow rays, [4s+3] fetch cursor of a shadow-only launch
     uint32_t n_slots;        ///< path slots per pass (pixels of the tile, 8x8-tile padded)
     uint32_t batch;          ///< passes processed together: slot s belongs to pass s / n_slots, pixel slot s % n_slots
     uint32_t tile_pixels;    ///< stride between the passes' colour planes in `passcolor`
