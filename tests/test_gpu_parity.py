@@ -546,32 +546,32 @@ def test_full_size_accumulation_is_additive(B, be, O, dragon_1080p):
     np.testing.assert_array_equal(d1, d2)
 
 
-@pytest.mark.parametrize("plan", [0, 7, 70, 1000])
-def test_pass_grouping_never_changes_the_result(B, be, O, plan):
+@pytest.mark.parametrize("plan,npaths", [(0, 1), (7, 1), (70, 1), (1000, 1), (70, 3)])
+def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths):
     """gpuart_hip_pt_pass only queues; passes travel through the pipeline in runs whose size follows the plan hint
     (gpuart_hip_pt_plan), the tile size and explicit flushes. Whatever the grouping — one pass at a time with a read-back
-    after each, runs of up to 64 passes on a small tile, flushes in odd places — the accumulator is the float32 sum of
-    the single passes in pass order (path_tracing.glsl:255), and equals the oracle's."""
+    after each, runs of up to 64 passes on a small tile, flushes in odd places, several paths per pass — the accumulator
+    is the float32 sum of the single passes in pass order (path_tracing.glsl:252-255), and equals the oracle's."""
     W, H = 64, 40
     cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
     c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
     tree, _ = O.build_bvh(scene("box"))
     sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
     P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
-    K = 70
+    K = 70 if npaths == 1 else 20
     seeds = O.randseeds(K)
     be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
     # one pass at a time, observed after each: the reference's own schedule
     be.pt_reset()
     for k in range(K):
-        be.pt_pass(to_params(B, P), seeds[k], 1)
+        be.pt_pass(to_params(B, P), seeds[k], npaths)
         if k % 9 == 0:
             be.read(1)
     step_by_step = be.read(1)
     # queued with a plan, flushed in odd places
     be.pt_reset(); be.pt_plan(plan)
     for k in range(K):
-        be.pt_pass(to_params(B, P), seeds[k], 1)
+        be.pt_pass(to_params(B, P), seeds[k], npaths)
         if k in (3, 4, 40):
             be.flush()
     grouped = be.read(1)
@@ -579,7 +579,7 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan):
     if plan == 70:
         acc = np.zeros((H, W, 4), np.float32)
         for k in range(K):
-            O.pt_pass(tree, c, W, H, P, seeds[k], 1, acc)
+            O.pt_pass(tree, c, W, H, P, seeds[k], npaths, acc)
         assert_bits(grouped[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "vs oracle")
 
 
