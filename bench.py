@@ -47,12 +47,19 @@ def main():
     ap.add_argument("--frame", default="1920x1080",
                     help="frame size WxH (default: cfg3's 1080p, the configuration the metric is quoted on; 3840x2160 = "
                          "the 4K frame north_star also asks for — see DESIGN.md for its numbers)")
+    ap.add_argument("--workload", choices=["cfg3", "cfg2"], default="cfg3",
+                    help="cfg3 (default, the configuration the metric is quoted on): Scene D, depth 8; cfg2 of BASELINE.json: "
+                         "the primitives-only Scene P (spheres + discs), depth 4, default camera")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true",
                     help="rank 0 also renders the whole frame alone and checks the gathered frame against it bit for bit")
     args = ap.parse_args()
-    global W, H
+    global W, H, MAX_SEGMENTS
     W, H = (int(x) for x in args.frame.lower().split("x"))
+    cfg2 = args.workload == "cfg2"
+    scene_descs = S.scene_p() if cfg2 else S.scene_d()
+    if cfg2:
+        MAX_SEGMENTS = 4
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,10 +83,10 @@ def main():
     torch.cuda.set_device(dev)
 
     # ---- scene + renderer (gpuart::Renderer API; scene build is not part of the timed region) ----
-    cam = dict(S.BENCH_CAMERA)
+    cam = dict(S.DEFAULT_CAMERA if cfg2 else S.BENCH_CAMERA)
     cam["dir"] = S.camera_dir(cam)
     t0 = time.time()
-    prims = B.make_prims(S.scene_d())
+    prims = B.make_prims(scene_descs)
     r = B.Renderer(W, H, cam, device=local_rank)
     r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
     r.set_primitives(prims)
@@ -197,7 +204,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box grants a 16-core CPU share per GPU
-        otree, _ = O.build_bvh(S.scene_d())
+        otree, _ = O.build_bvh(scene_descs)
         c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
         sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
         P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], MAX_SEGMENTS, 0.01)
@@ -206,7 +213,7 @@ def main():
         st = O.pt_pass(otree, c, W, H, P, O.randseeds(1)[0], 1, acc, nthreads=cores)
         dt = time.perf_counter() - t1
         cpu_baseline = {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                        "sample": "1 full pass of the same workload (%dx%d Scene D, depth 8, seed pass 0): " % (W, H) +
+                        "sample": "1 full pass of the same workload (%dx%d, depth %d, seed pass 0): " % (W, H, MAX_SEGMENTS) +
                                   "%d rays in %.2f s; strict-fp32 CPU restatement, %d threads" % (st.rays, dt, cores),
                         "ms_per_frame": round(dt * 1e3, 1)}
 
@@ -223,10 +230,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": ("cfg3" if (W, H) == (1920, 1080) else "cfg3 at another frame size") +
-                               ": Scene D (dragon-class, 100352 triangles + floor disc), %dx%d, path tracing " % (W, H) +
-                               "depth 8 (MAX_PATH_SEGMENTS=8, MIN_WEIGHT=0.01), 1 path/pixel/pass, Sun direct lighting on, "
-                               "benchmark camera",
+        "config": {"workload": (args.workload if (W, H) == (1920, 1080) else args.workload + " at another frame size") +
+                               (": Scene P (256 spheres + 16 discs), " if cfg2 else
+                                ": Scene D (dragon-class, 100352 triangles + floor disc), ") + "%dx%d, path tracing " % (W, H) +
+                               "depth %d (MAX_PATH_SEGMENTS=%d, MIN_WEIGHT=0.01), 1 path/pixel/pass, Sun direct lighting on, "
+                               % (MAX_SEGMENTS, MAX_SEGMENTS) + ("default camera" if cfg2 else "benchmark camera"),
                    "frame": [W, H], "parallelism": "8-row screen bands interleaved over %d rank(s)" % world,
                    "bvh_nodes": info["nodes"], "bvh_primitives": info["prims"], "bvh_depth": info["max_depth"],
                    "scene_device_bytes": info["device_bytes"], "scene_setup_s": round(setup_s, 3)},
