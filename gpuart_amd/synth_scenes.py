@@ -119,3 +119,53 @@ def write_ply(path, model, faces):
             f.write("%.9g %.9g %.9g\n" % (x, y, z))
         for a, b, c in faces:
             f.write("3 %d %d %d\n" % (a, b, c))
+
+
+def random_case(seed):
+    """A random parity case (tools/fuzz_parity.py, tests/golden `fuzz`): primitives of all four types incl. degenerate
+    ones (zero radii, zero-area and axis-aligned triangles, exact duplicates, cylinders), frame size, camera, user
+    sphere, Sun, path depth, paths per pass. Everything is drawn from RandomState(seed) in a fixed order."""
+    rs = np.random.RandomState(seed)
+    prims = []
+    if rs.rand() < 0.8:
+        prims.append((DISC, [0, 0, 0, 0, 0, 1, f32(rs.uniform(2, 6))]))
+    n = int(rs.choice([0, 1, 2, 3, 8, 40, 200]))
+    for _ in range(n):
+        t = rs.randint(4)
+        p = rs.uniform(-1.5, 1.5, 3); p[2] = abs(p[2])
+        if t == SPHERE:
+            r = rs.choice([0.0, rs.uniform(0.02, 0.4)], p=[0.05, 0.95])
+            prims.append((SPHERE, [f32(p[0]), f32(p[1]), f32(p[2]), f32(r)]))
+        elif t == DISC:
+            nrm = rs.normal(size=3); nrm /= np.linalg.norm(nrm)
+            if rs.rand() < 0.3:
+                nrm = np.eye(3)[rs.randint(3)] * rs.choice([-1, 1])
+            prims.append((DISC, [f32(p[0]), f32(p[1]), f32(p[2]), f32(nrm[0]), f32(nrm[1]), f32(nrm[2]), f32(rs.uniform(0, 0.5))]))
+        elif t == TRIANGLE:
+            a = p; b = p + rs.uniform(-0.5, 0.5, 3); c = p + rs.uniform(-0.5, 0.5, 3)
+            mode = rs.rand()
+            if mode < 0.15:   # axis-aligned flat triangle
+                k = rs.randint(3); b[k] = a[k]; c[k] = a[k]
+            elif mode < 0.2:  # zero area
+                c = b.copy()
+            tri = (TRIANGLE, [f32(x) for x in np.concatenate([a, b, c])])
+            prims.append(tri)
+            if rs.rand() < 0.1:
+                prims.append(tri)  # exact duplicate: equal hit parameters, the first one must win
+        else:
+            q = p + rs.uniform(-0.4, 0.4, 3)
+            r1, r2 = rs.uniform(0.0, 0.25, 2)
+            if rs.rand() < 0.2:
+                r2 = r1
+            prims.append((CONE, [f32(p[0]), f32(p[1]), f32(p[2]), f32(q[0]), f32(q[1]), f32(q[2]), f32(r1), f32(r2)]))
+    W, H = int(rs.choice([17, 40, 64, 96])), int(rs.choice([9, 24, 48]))
+    pos = rs.uniform(-2.5, 2.5, 3); pos[2] = abs(pos[2]) + 0.05
+    target = rs.uniform(-0.5, 0.5, 3); target[2] = abs(target[2])
+    d = target - pos; d /= np.linalg.norm(d)
+    cam = dict(pos=tuple(float(f32(x)) for x in pos), dir=tuple(float(f32(x)) for x in d), up=(0.0, 0.0, 1.0),
+               fov_y=float(f32(rs.uniform(30, 90))), screen_dist=0.2)
+    flags = int(rs.choice([0, 0, 1, 2, 6]))
+    us = (float(f32(rs.uniform(-1, 1))), float(f32(rs.uniform(-1, 1))), float(f32(rs.uniform(0.2, 1))), float(rs.choice([0.0, 0.25])))
+    return dict(prims=prims, W=W, H=H, cam=cam, us_flags=flags, user_sphere=us, us_em=3.0 if flags & 1 else 0.0,
+                sun_az=float(f32(rs.uniform(0, 6.28))), sun_alt=float(f32(rs.uniform(0.1, 1.5))), sun_on=bool(rs.rand() < 0.8),
+                max_segments=int(rs.choice([1, 3, 5, 8])), npaths=int(rs.choice([1, 1, 2])), passes=3)

@@ -441,9 +441,35 @@ def gen_frames(gl):
              user_sphere_em=em, user_sphere_flags=flags, seeds=seeds, **out)
 
 
+def gen_fuzz(gl):
+    """Random cases of gpuart_amd.synth_scenes.random_case (degenerate primitives, duplicates, random cameras / user
+    sphere / Sun / depth) rendered by the reference's shaders: direct lighting + `passes` accumulated path-tracing passes.
+    Pins the oracle on inputs nobody hand-picked."""
+    progs = {}
+    out = {}
+    cases = list(range(24))
+    for seed in cases:
+        case = S.random_case(seed)
+        tree, _ = O.build_bvh(case["prims"])
+        ms = case["max_segments"]
+        if ms not in progs:
+            progs[ms] = RefPrograms(gl, ms)
+        r = RefRenderer(gl, progs[ms], case["W"], case["H"], case["cam"], tree)
+        r.us, r.us_em, r.us_flags = case["user_sphere"], case["us_em"], case["us_flags"]
+        r.sun_az, r.sun_alt, r.sun_on = case["sun_az"], case["sun_alt"], int(case["sun_on"])
+        seeds = O.randseeds(case["passes"], seed=5489 + seed)
+        out["direct_%d" % seed] = r.direct()[..., :3].copy()
+        r.reset()
+        for k in range(case["passes"]):
+            acc = r.pt_pass(case["npaths"], seeds[k])
+        out["pt_acc_%d" % seed] = acc[..., :3].copy()
+        print("  fuzz case %d: %d primitives, %dx%d, depth %d, flags %d" % (seed, len(case["prims"]), case["W"], case["H"], ms, case["us_flags"]))
+    save("fuzz_frames", cases=np.array(cases, np.int32), **out)
+
+
 SECTIONS = dict(hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
                 disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
-                traverse=gen_traverse, frames=gen_frames)
+                traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz)
 
 if __name__ == "__main__":
     if not glref.available():

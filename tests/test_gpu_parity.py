@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from gpuart_amd import synth_scenes as S
-from tests.util import GOLDEN, assert_bits, bit_mismatch, frame_golden_params, golden, pad4, rmse_per_channel, scene
+from tests.util import fuzz_case_setup, GOLDEN, assert_bits, bit_mismatch, frame_golden_params, golden, pad4, rmse_per_channel, scene
 
 pytestmark = pytest.mark.gpu
 
@@ -615,6 +615,25 @@ def test_scheduling_knobs_never_change_the_result(B, O, env, monkeypatch):
     finally:
         b.close()
     assert_bits(got[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "knobs %s" % env)
+
+
+def test_random_cases_vs_reference_goldens(B, be, O):
+    """The 24 random cases rendered by the reference's shaders on llvmpipe (tests/golden/fuzz_frames.npz): the HIP path
+    reproduces direct lighting and the accumulated path-tracing passes bit for bit, wavefront and megakernel mode."""
+    g = golden("fuzz_frames")
+    for seed in g["cases"]:
+        seed = int(seed)
+        case, tree, cam, P, seeds = fuzz_case_setup(O, seed)
+        be.resize(case["W"], case["H"]); be.upload_bvh(tree); be.set_camera(cam)
+        for mode in (0, 2):
+            be.set_mode(mode)
+            be.render_direct(to_params(B, P))
+            assert_bits(be.read(0)[..., :3].reshape(-1, 3), g["direct_%d" % seed].reshape(-1, 3), "case %d direct, mode %d" % (seed, mode))
+            be.pt_reset()
+            for k in range(case["passes"]):
+                be.pt_pass(to_params(B, P), seeds[k], case["npaths"])
+            assert_bits(be.read(1)[..., :3].reshape(-1, 3), g["pt_acc_%d" % seed].reshape(-1, 3), "case %d PT, mode %d" % (seed, mode))
+        be.set_mode(0)
 
 
 def test_random_scenes_soak():

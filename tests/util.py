@@ -59,3 +59,16 @@ def frame_golden_params(O, g):
     ms = int(g["max_segments"]) if "max_segments" in g else 5
     sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
     return lambda sun_on=True: O.make_params(sun, S.SUN_ALTITUDE, sun_on, us, em, fl, float(cam[12]), cam[0:3], ms, 0.01)
+
+
+def fuzz_case_setup(O, seed):
+    """(case, tree, camera, params, seeds) of random case `seed` (gpuart_amd.synth_scenes.random_case), as
+    tests/golden/make_golden.py `fuzz` and tools/fuzz_parity.py set it up."""
+    case = S.random_case(seed)
+    cd = case["cam"]
+    cam = O.camera(cd["pos"], cd["dir"], cd["up"], cd["fov_y"], cd["screen_dist"], case["W"], case["H"])
+    tree, _ = O.build_bvh(case["prims"])
+    sun = O.sun_direction(case["sun_az"], case["sun_alt"])
+    P = O.make_params(sun, case["sun_alt"], case["sun_on"], case["user_sphere"], case["us_em"], case["us_flags"], float(cam[12]),
+                      cam[0:3], case["max_segments"], 0.01)
+    return case, tree, cam, P, O.randseeds(case["passes"], seed=5489 + seed)

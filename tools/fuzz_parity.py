@@ -17,64 +17,22 @@ from oracle import oracle as O  # noqa: E402
 f32 = np.float32
 
 
-def random_scene(rs):
-    prims = []
-    if rs.rand() < 0.8:
-        prims.append((S.DISC, [0, 0, 0, 0, 0, 1, f32(rs.uniform(2, 6))]))
-    n = int(rs.choice([0, 1, 2, 3, 8, 40, 200]))
-    for _ in range(n):
-        t = rs.randint(4)
-        p = rs.uniform(-1.5, 1.5, 3); p[2] = abs(p[2])
-        if t == S.SPHERE:
-            r = rs.choice([0.0, rs.uniform(0.02, 0.4)], p=[0.05, 0.95])
-            prims.append((S.SPHERE, [f32(p[0]), f32(p[1]), f32(p[2]), f32(r)]))
-        elif t == S.DISC:
-            nrm = rs.normal(size=3); nrm /= np.linalg.norm(nrm)
-            if rs.rand() < 0.3:
-                nrm = np.eye(3)[rs.randint(3)] * rs.choice([-1, 1])
-            prims.append((S.DISC, [f32(p[0]), f32(p[1]), f32(p[2]), f32(nrm[0]), f32(nrm[1]), f32(nrm[2]), f32(rs.uniform(0, 0.5))]))
-        elif t == S.TRIANGLE:
-            a = p; b = p + rs.uniform(-0.5, 0.5, 3); c = p + rs.uniform(-0.5, 0.5, 3)
-            mode = rs.rand()
-            if mode < 0.15:   # axis-aligned flat triangle
-                k = rs.randint(3); b[k] = a[k]; c[k] = a[k]
-            elif mode < 0.2:  # zero area
-                c = b.copy()
-            tri = (S.TRIANGLE, [f32(x) for x in np.concatenate([a, b, c])])
-            prims.append(tri)
-            if rs.rand() < 0.1:
-                prims.append(tri)  # exact duplicate: equal hit parameters, the first one must win
-        else:
-            q = p + rs.uniform(-0.4, 0.4, 3)
-            r1, r2 = rs.uniform(0.0, 0.25, 2)
-            if rs.rand() < 0.2:
-                r2 = r1
-            prims.append((S.CONE, [f32(p[0]), f32(p[1]), f32(p[2]), f32(q[0]), f32(q[1]), f32(q[2]), f32(r1), f32(r2)]))
-    return prims
-
-
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     be = B.Backend(0)
     bad = 0
     for seed in range(first, first + count):
-        rs = np.random.RandomState(seed)
-        prims = random_scene(rs)
-        W, H = int(rs.choice([17, 40, 64, 96])), int(rs.choice([9, 24, 48]))
-        pos = rs.uniform(-2.5, 2.5, 3); pos[2] = abs(pos[2]) + 0.05
-        target = rs.uniform(-0.5, 0.5, 3); target[2] = abs(target[2])
-        d = target - pos; d /= np.linalg.norm(d)
-        cam = O.camera(pos.astype(f32), d.astype(f32), (0.0, 0.0, 1.0), float(rs.uniform(30, 90)), 0.2, W, H)
-        tree, _ = O.build_bvh(prims) if prims else O.build_bvh([])
-        flags = int(rs.choice([0, 0, 1, 2, 6]))
-        us = (float(rs.uniform(-1, 1)), float(rs.uniform(-1, 1)), float(rs.uniform(0.2, 1)), float(rs.choice([0.0, 0.25])))
-        em = 3.0 if flags & 1 else 0.0
-        sun = O.sun_direction(float(rs.uniform(0, 6.28)), float(rs.uniform(0.1, 1.5)))
-        alt = float(rs.uniform(0.1, 1.5))
-        P = O.make_params(sun, alt, bool(rs.rand() < 0.8), us, em, flags, float(cam[12]), cam[0:3],
-                          int(rs.choice([1, 3, 5, 8])), 0.01)
-        K, npaths = 3, int(rs.choice([1, 1, 2]))
+        case = S.random_case(seed)
+        prims, W, H = case["prims"], case["W"], case["H"]
+        cd = case["cam"]
+        cam = O.camera(cd["pos"], cd["dir"], cd["up"], cd["fov_y"], cd["screen_dist"], W, H)
+        tree, _ = O.build_bvh(prims)
+        flags = case["us_flags"]
+        sun = O.sun_direction(case["sun_az"], case["sun_alt"])
+        P = O.make_params(sun, case["sun_alt"], case["sun_on"], case["user_sphere"], case["us_em"], flags, float(cam[12]),
+                          cam[0:3], case["max_segments"], 0.01)
+        K, npaths = case["passes"], case["npaths"]
         seeds = O.randseeds(K, seed=5489 + seed)
         exp_direct, _ = O.render_direct(tree, cam, W, H, P)
         acc = np.zeros((H, W, 4), f32)
