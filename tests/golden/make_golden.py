@@ -467,9 +467,30 @@ def gen_fuzz(gl):
     save("fuzz_frames", cases=np.array(cases, np.int32), **out)
 
 
+def row_checksums(img):
+    """Per row and channel: sum of the float32 bit patterns (uint64) — order-independent inside a row, exact."""
+    return img[..., :3].view(np.uint32).astype(np.uint64).sum(axis=1)
+
+
+def gen_fullsize(gl):
+    """BASELINE cfg3 at its full size (Scene D, 1920x1080, depth 8, benchmark camera) rendered by the reference's
+    shaders; stored as per-row checksums of the bit patterns (a 1080p RGBA32F frame is 33 MB)."""
+    _, tree, _ = scene_tree("scene_d")
+    W, H = 1920, 1080
+    progs = RefPrograms(gl, 8)
+    r = RefRenderer(gl, progs, W, H, default_cam(S.BENCH_CAMERA), tree)
+    seeds = O.randseeds(2)
+    out = {"direct": row_checksums(r.direct())}
+    r.reset()
+    for k in range(2):
+        acc = r.pt_pass(1, seeds[k])
+        out["pt_acc%d" % (k + 1)] = row_checksums(acc)
+    save("fullsize_scene_d_1080p", W=W, H=H, cam=r.cam, max_segments=8, seeds=seeds, **out)
+
+
 SECTIONS = dict(hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
                 disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
-                traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz)
+                traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":
     if not glref.available():

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from gpuart_amd import synth_scenes as S
-from tests.util import fuzz_case_setup, GOLDEN, assert_bits, bit_mismatch, frame_golden_params, golden, pad4, rmse_per_channel, scene
+from tests.util import fuzz_case_setup, row_checksums, GOLDEN, assert_bits, bit_mismatch, frame_golden_params, golden, pad4, rmse_per_channel, scene
 
 pytestmark = pytest.mark.gpu
 
@@ -634,6 +634,25 @@ def test_random_cases_vs_reference_goldens(B, be, O):
                 be.pt_pass(to_params(B, P), seeds[k], case["npaths"])
             assert_bits(be.read(1)[..., :3].reshape(-1, 3), g["pt_acc_%d" % seed].reshape(-1, 3), "case %d PT, mode %d" % (seed, mode))
         be.set_mode(0)
+
+
+def test_full_size_frame_vs_reference_checksums(B, be, O):
+    """BASELINE cfg3 at FULL size as rendered by the reference's shaders on llvmpipe (per-row checksums of the float bit
+    patterns, tests/golden/fullsize_scene_d_1080p.npz): the HIP path's direct-lighting frame and its accumulator after
+    one and two passes give the same checksums — full-size parity against the reference itself, not only the oracle."""
+    g = golden("fullsize_scene_d_1080p")
+    W, H = int(g["W"]), int(g["H"])
+    tree, _ = O.build_bvh(scene("scene_d"))
+    cam = g["cam"]
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], int(g["max_segments"]), 0.01)
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
+    be.render_direct(to_params(B, P))
+    np.testing.assert_array_equal(row_checksums(be.read(0)), g["direct"])
+    be.pt_reset()
+    for k in range(2):
+        be.pt_pass(to_params(B, P), g["seeds"][k], 1)
+        np.testing.assert_array_equal(row_checksums(be.read(1)), g["pt_acc%d" % (k + 1)])
 
 
 def test_random_scenes_soak():

@@ -8,8 +8,9 @@ import os
 import numpy as np
 import pytest
 
+from gpuart_amd import synth_scenes as S
 from oracle import oracle as O
-from tests.util import fuzz_case_setup, GOLDEN, assert_bits, frame_golden_params, golden, pad4, scene
+from tests.util import fuzz_case_setup, row_checksums, GOLDEN, assert_bits, frame_golden_params, golden, pad4, scene
 
 
 def test_hash_random():
@@ -176,6 +177,24 @@ def test_random_cases_vs_reference():
         for k in range(case["passes"]):
             O.pt_pass(tree, cam, W, H, P, seeds[k], case["npaths"], acc)
         assert_bits(acc[..., :3].reshape(-1, 3), g["pt_acc_%d" % seed].reshape(-1, 3), "case %d path tracing" % seed)
+
+
+def test_full_size_frame_vs_reference_checksums():
+    """BASELINE cfg3 at FULL size (Scene D, 1920x1080, depth 8, benchmark camera) as rendered by the reference's shaders
+    on llvmpipe, held as per-row checksums of the float bit patterns: the oracle's direct-lighting frame and its
+    accumulator after one and two path-tracing passes give the same 3 x 1080 x 3 checksums."""
+    g = golden("fullsize_scene_d_1080p")
+    W, H = int(g["W"]), int(g["H"])
+    tree, _ = O.build_bvh(scene("scene_d"))
+    cam = g["cam"]
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], int(g["max_segments"]), 0.01)
+    nt = min(8, os.cpu_count() or 1)
+    np.testing.assert_array_equal(row_checksums(O.render_direct(tree, cam, W, H, P, nthreads=nt)[0]), g["direct"])
+    acc = np.zeros((H, W, 4), np.float32)
+    for k in range(2):
+        O.pt_pass(tree, cam, W, H, P, g["seeds"][k], 1, acc, nthreads=nt)
+        np.testing.assert_array_equal(row_checksums(acc), g["pt_acc%d" % (k + 1)])
 
 
 def test_randseed_sequence():

@@ -72,3 +72,8 @@ def fuzz_case_setup(O, seed):
     P = O.make_params(sun, case["sun_alt"], case["sun_on"], case["user_sphere"], case["us_em"], case["us_flags"], float(cam[12]),
                       cam[0:3], case["max_segments"], 0.01)
     return case, tree, cam, P, O.randseeds(case["passes"], seed=5489 + seed)
+
+
+def row_checksums(img):
+    """Per row and channel: sum of the float32 bit patterns (uint64), as tests/golden/make_golden.py `fullsize` stores them."""
+    return np.ascontiguousarray(img[..., :3], np.float32).view(np.uint32).astype(np.uint64).sum(axis=1)
