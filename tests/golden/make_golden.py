@@ -473,19 +473,21 @@ def row_checksums(img):
 
 
 def gen_fullsize(gl):
-    """BASELINE cfg3 at its full size (Scene D, 1920x1080, depth 8, benchmark camera) rendered by the reference's
-    shaders; stored as per-row checksums of the bit patterns (a 1080p RGBA32F frame is 33 MB)."""
+    """BASELINE cfg3 / cfg4 at their full sizes (Scene D, depth 8, benchmark camera; 1920x1080 and 3840x2160) rendered by
+    the reference's shaders; stored as per-row checksums of the bit patterns (a 1080p RGBA32F frame is 33 MB)."""
     _, tree, _ = scene_tree("scene_d")
-    W, H = 1920, 1080
     progs = RefPrograms(gl, 8)
-    r = RefRenderer(gl, progs, W, H, default_cam(S.BENCH_CAMERA), tree)
-    seeds = O.randseeds(2)
-    out = {"direct": row_checksums(r.direct())}
-    r.reset()
-    for k in range(2):
-        acc = r.pt_pass(1, seeds[k])
-        out["pt_acc%d" % (k + 1)] = row_checksums(acc)
-    save("fullsize_scene_d_1080p", W=W, H=H, cam=r.cam, max_segments=8, seeds=seeds, **out)
+    for tag, W, H, npass in (("1080p", 1920, 1080, 2), ("4k", 3840, 2160, 1)):
+        r = RefRenderer(gl, progs, W, H, default_cam(S.BENCH_CAMERA), tree)
+        seeds = O.randseeds(2)
+        out = {"direct": row_checksums(r.direct())}
+        r.reset()
+        for k in range(npass):
+            acc = r.pt_pass(1, seeds[k])
+            out["pt_acc%d" % (k + 1)] = row_checksums(acc)
+        save("fullsize_scene_d_" + tag, W=W, H=H, cam=r.cam, max_segments=8, seeds=seeds, npasses=npass, **out)
+        for t in (r.rstart, r.rdir, r.out, *r.acc):
+            gl.L.glref_delete_tex(t)
 
 
 SECTIONS = dict(hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,

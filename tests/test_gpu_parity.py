@@ -636,11 +636,12 @@ def test_random_cases_vs_reference_goldens(B, be, O):
         be.set_mode(0)
 
 
-def test_full_size_frame_vs_reference_checksums(B, be, O):
+@pytest.mark.parametrize("tag", ["1080p", "4k"])
+def test_full_size_frame_vs_reference_checksums(B, be, O, tag):
     """BASELINE cfg3 at FULL size as rendered by the reference's shaders on llvmpipe (per-row checksums of the float bit
     patterns, tests/golden/fullsize_scene_d_1080p.npz): the HIP path's direct-lighting frame and its accumulator after
     one and two passes give the same checksums — full-size parity against the reference itself, not only the oracle."""
-    g = golden("fullsize_scene_d_1080p")
+    g = golden("fullsize_scene_d_" + tag)
     W, H = int(g["W"]), int(g["H"])
     tree, _ = O.build_bvh(scene("scene_d"))
     cam = g["cam"]
@@ -650,7 +651,7 @@ def test_full_size_frame_vs_reference_checksums(B, be, O):
     be.render_direct(to_params(B, P))
     np.testing.assert_array_equal(row_checksums(be.read(0)), g["direct"])
     be.pt_reset()
-    for k in range(2):
+    for k in range(int(g["npasses"])):
         be.pt_pass(to_params(B, P), g["seeds"][k], 1)
         np.testing.assert_array_equal(row_checksums(be.read(1)), g["pt_acc%d" % (k + 1)])
 

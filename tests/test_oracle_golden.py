@@ -179,11 +179,12 @@ def test_random_cases_vs_reference():
         assert_bits(acc[..., :3].reshape(-1, 3), g["pt_acc_%d" % seed].reshape(-1, 3), "case %d path tracing" % seed)
 
 
-def test_full_size_frame_vs_reference_checksums():
+@pytest.mark.parametrize("tag", ["1080p", "4k"])
+def test_full_size_frame_vs_reference_checksums(tag):
     """BASELINE cfg3 at FULL size (Scene D, 1920x1080, depth 8, benchmark camera) as rendered by the reference's shaders
     on llvmpipe, held as per-row checksums of the float bit patterns: the oracle's direct-lighting frame and its
     accumulator after one and two path-tracing passes give the same 3 x 1080 x 3 checksums."""
-    g = golden("fullsize_scene_d_1080p")
+    g = golden("fullsize_scene_d_" + tag)
     W, H = int(g["W"]), int(g["H"])
     tree, _ = O.build_bvh(scene("scene_d"))
     cam = g["cam"]
@@ -192,7 +193,7 @@ def test_full_size_frame_vs_reference_checksums():
     nt = min(8, os.cpu_count() or 1)
     np.testing.assert_array_equal(row_checksums(O.render_direct(tree, cam, W, H, P, nthreads=nt)[0]), g["direct"])
     acc = np.zeros((H, W, 4), np.float32)
-    for k in range(2):
+    for k in range(int(g["npasses"])):
         O.pt_pass(tree, cam, W, H, P, g["seeds"][k], 1, acc, nthreads=nt)
         np.testing.assert_array_equal(row_checksums(acc), g["pt_acc%d" % (k + 1)])
 
