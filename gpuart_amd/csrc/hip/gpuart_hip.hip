@@ -86,12 +86,14 @@ struct gpuart_hip_ctx {
     Frame frame{};
     bool have_camera = false, have_scene = false;
     float4 *d_recs = nullptr, *d_prims = nullptr;
+    uint32_t *d_cursor = nullptr;  ///< pixel cursor of k_direct_persistent
     uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow for kernels on the primary stream
     std::vector<PassLane> lanes;
     uint32_t next_lane = 0;
     uint32_t spill_levels = 0;
     uint32_t num_cus = 256;
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
+    uint32_t direct_waves = 4096;  ///< grid of k_direct_persistent (runs alone: needs the whole occupancy itself)
     uint32_t shade_waves = 4096;   ///< grid of the streaming kernels (k_gen, k_shade): latency-bound, so more waves than k_trace
     TraceTuning tune{128, 16, 16, 3};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
@@ -243,7 +245,7 @@ int ensure_spill(gpuart_hip_ctx *c) {
     if (c->d_spill && c->spill_levels >= levels) return 0;
     int r = drain(c);
     if (r) return r;
-    const size_t bytes = ((size_t)levels + 1) * c->grid_waves * BLOCK * sizeof(uint4);
+    const size_t bytes = ((size_t)levels + 1) * std::max(c->grid_waves, c->direct_waves) * BLOCK * sizeof(uint4);
     if (c->d_spill) { (void)hipFree(c->d_spill); c->d_spill = nullptr; }
     HIP_TRY(hipMalloc(&c->d_spill, bytes));
     for (auto &l : c->lanes) {
@@ -379,6 +381,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     };
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 8, 1, 32);  // persistent grids of one-wave workgroups
+    c->direct_waves = c->num_cus * env_u32("GPUART_HIP_DIRECT_WAVES_PER_CU", 16, 1, 32);
     c->shade_waves = c->num_cus * env_u32("GPUART_HIP_SHADE_WAVES_PER_CU", 24, 1, 64);
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 128, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
@@ -422,7 +425,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
         for (void *p : lp) if (p) (void)hipFree(p);
         if (l.main) (void)hipStreamDestroy(l.main);
     }
-    void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch};
+    void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -514,8 +517,19 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
     Scene sc = scene_of(c);
     TimedLaunch t;
     if ((r = begin_timed(c, t, 0))) return r;
-    if (c->mode == 1) k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
-    else k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
+    if (c->mode == 1) {
+        k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
+    } else if (c->mode == 2) {
+        k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
+    } else {
+        // fast mode: persistent lanes, one pixel at a time per lane (kernels_pipeline.h)
+        if (!c->d_cursor) HIP_TRY(hipMalloc(&c->d_cursor, 64));
+        HIP_TRY(hipMemsetAsync(c->d_cursor, 0, sizeof(uint32_t), c->stream));
+        const dim3 pgrid(c->direct_waves);  // alone on the GPU: 16 waves per CU measured best
+        const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;
+        if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
+        else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
+    }
     HIP_TRY(hipGetLastError());
     return end_timed(c, t);
 }

@@ -358,6 +358,149 @@ __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_para
     if (REFWORK) flush_counters(wc, 0, counters);
 }
 
+// ---- direct lighting with persistent lanes ------------------------------------------------------------
+// One kernel, as k_direct, but a lane does not wait for its wave: it carries one pixel through the queries of
+// direct_lighting.glsl:134-207 (primary ray, at most one mirror bounce off a specular user sphere, Sun-shadow query,
+// query towards an emissive user sphere) as a small state machine and takes the next pixel from a shared cursor when it
+// is done, so that all 64 lanes keep traversing (the loop of k_trace). The arithmetic per pixel is that of
+// direct_lighting_pixel, operation for operation; the terms that wait for a visibility answer are computed before the
+// query is issued and added, in the shader's order, when the answer arrives. Single kernel: no chain of dependent
+// launches, which is what the interactive mode needs (one frame, then display).
+enum { DL_PRIMARY = 0, DL_SUN = 1, DL_EM = 2 };
+
+template <int TYPES>
+__global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_direct_persistent(Scene sc, Frame f, gpuart_params P, uint32_t n_slots,
+                                                                          float4 *__restrict__ out, uint4 *spill, uint32_t *cursor,
+                                                                          TraceTuning tune) {
+    __shared__ uint2 ring_a[GD_RING * BLOCK];
+    __shared__ float ring_b[GD_RING * BLOCK];
+    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
+    const float AMBIENT = 0.15f;
+    const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
+    const F3 usc = f3(P.userSphere[0], P.userSphere[1], P.userSphere[2]);
+    const uint32_t n = n_slots;
+    const uint32_t static_end = gridDim.x * tune.chunk;
+    uint32_t chunk_next = min(blockIdx.x * tune.chunk, n), chunk_end = min((blockIdx.x + 1) * tune.chunk, n);  // wave-uniform
+    bool exhausted = false;                                                                                   // wave-uniform
+    uint32_t pixel = SLOT_INVALID;          // index into `out` of the pixel this lane works on
+    int stage = DL_PRIMARY, bounce = 0;
+    F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0), rdiv = f3(1, 1, 1);
+    F3 cw = f3(1, 1, 1), acc = f3(0, 0, 0), sun_term = f3(0, 0, 0), em_term = f3(0, 0, 0), em_dir = f3(0, 0, 0), ambient = f3(0, 0, 0);
+    float em_dist = 0;
+    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+
+    auto start_query = [&](F3 o, F3 d) {
+        ro = o; rd = d;
+        rdiv = f3(1 / d.x, 1 / d.y, 1 / d.z);
+        trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
+    };
+
+    for (;;) {
+        // ---- idle lanes take the next pixels
+        unsigned long long idle = __ballot(pixel == SLOT_INVALID);
+        while (idle && !exhausted) {
+            if (chunk_next == chunk_end) {
+                if (static_end >= n) { exhausted = true; break; }
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(cursor, tune.chunk);
+                base = __shfl(base, 0, 64) + static_end;
+                if (base >= n) { exhausted = true; break; }
+                chunk_next = base;
+                chunk_end = min(base + tune.chunk, n);
+            }
+            uint32_t want = (uint32_t)__popcll(idle), take = min(want, chunk_end - chunk_next);
+            uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1));
+            if (pixel == SLOT_INVALID && rank < take) {
+                uint32_t lx, ly;
+                if (slot_pixel(f, chunk_next + rank, lx, ly)) {
+                    pixel = ly * f.tw + lx;
+                    F3 rs0, rd0;
+                    camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
+                    cw = f3(1, 1, 1); acc = f3(0, 0, 0);
+                    stage = DL_PRIMARY; bounce = 0;
+                    start_query(rs0, rd0);
+                }
+            }
+            chunk_next += take;
+            idle = __ballot(pixel == SLOT_INVALID);
+            if (take == want) break;
+        }
+        if (__ballot(pixel != SLOT_INVALID) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- traverse until enough lanes have an answer (a lane without a pixel is in state DONE)
+        for (;;) {
+            if (t.state == TRAV_DESCEND) trav_step_box<false>(sc, Ray{ro, rd}, rdiv, t, st, nullptr);
+            unsigned long long at_leaf = __ballot((t.state & 1) != 0);
+            unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
+            const uint32_t waiting = (uint32_t)__popcll(at_leaf);
+            if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
+                if (t.state & 1) {
+                    trav_step_leaf<false, false, TYPES>(sc, Ray{ro, rd}, t, st, nullptr);
+                    if (stage == DL_SUN && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;  // only "anything hit?" is asked
+                }
+                descending = __ballot(t.state == TRAV_DESCEND);
+                at_leaf = __ballot((t.state & 1) != 0);
+            }
+            unsigned long long busy = descending | at_leaf;
+            if (!busy) break;
+            if (64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
+        }
+        // ---- lanes with an answer move their pixel on (direct_lighting.glsl:134-207)
+        if (pixel != SLOT_INVALID && t.state == TRAV_DONE) {
+            bool finished = false;
+            if (stage == DL_PRIMARY) {
+                Surface h; bool ush;
+                resolve_hit(sc, Ray{ro, rd}, t.closest, t.hit_prim, P.userSphere, h, ush);
+                if ((P.userSphereFlags & 2u) && ush) {
+                    if (bounce == 0) {
+                        cw = cw * primitive_color(P_SPHERE);
+                        bounce = 1;
+                        start_query(h.p, reflect3(rd, h.n));
+                    } else {
+                        finished = true;  // the loop of the shader ends after its second iteration: out stays 0
+                    }
+                } else if ((P.userSphereFlags & 1u) && ush) {
+                    acc = f3(1, 1, 1);
+                    finished = true;
+                } else if (h.ptype != -1) {
+                    const F3 diffuse = primitive_color(h.ptype) * cw;
+                    ambient = AMBIENT * diffuse;
+                    sun_term = lambert(sun, h.n, diffuse);
+                    if (P.userSphereFlags & 1u) {
+                        const F3 dts = usc - h.p;
+                        em_dist = length3(dts);
+                        em_dir = f3(dts.x / em_dist, dts.y / em_dist, dts.z / em_dist);
+                        const F3 l = lambert(em_dir, h.n, diffuse);
+                        const float d2 = dot3(dts, dts);  // dist*dist: NIR folds sqrt(a)*sqrt(a) to |a|
+                        em_term = f3(l.x / d2, l.y / d2, l.z / d2);
+                    }
+                    if (P.sunEnabled == 1) { stage = DL_SUN; start_query(h.p, sun); }
+                    else if (P.userSphereFlags & 1u) { stage = DL_EM; start_query(h.p, em_dir); }
+                    else { acc = acc + ambient; finished = true; }
+                } else {
+                    acc = cw * sky_color(rd, P.sunDirAlt);
+                    finished = true;
+                }
+            } else if (stage == DL_SUN) {
+                if (sun_visible(P, ro, sun, t.hit_prim)) acc = acc + sun_term;
+                if (P.userSphereFlags & 1u) { stage = DL_EM; start_query(ro, em_dir); }
+                else { acc = acc + ambient; finished = true; }
+            } else {
+                if (t.hit_prim == GD_NO_PRIM || t.closest > em_dist) acc = acc + em_term;
+                acc = acc + ambient;
+                finished = true;
+            }
+            if (finished) {
+                out[pixel] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+                pixel = SLOT_INVALID;
+            }
+        }
+    }
+}
+
 template <bool REFWORK>
 __global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_params P, float4 seed, int npaths, uint32_t n_slots,
                                                    float4 *__restrict__ accum, uint4 *spill, unsigned long long *counters) {
