@@ -375,9 +375,14 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
     t.entry = 0;
     st.reset();
     if (count) { wc->rays++; wc->nodes++; }
-    float entry;
-    bool hit = aabb_entry(r, rdiv, f3(sc.root_min[0], sc.root_min[1], sc.root_min[2]),
-                          f3(sc.root_max[0], sc.root_max[1], sc.root_max[2]), entry);
+    // Rays that start inside the root box (nearly all: bounce and shadow rays leave surfaces, the camera usually stands
+    // inside the scene's box) are "hit, entry -1" by the inclusive inside test alone; the six face tests are only run
+    // when some lane of the wave starts outside.
+    const F3 bmin = f3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), bmax = f3(sc.root_max[0], sc.root_max[1], sc.root_max[2]);
+    const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
+    float entry = -1.0f;
+    bool hit = true;
+    if (__ballot(!inside) != 0) hit = aabb_entry(r, rdiv, bmin, bmax, entry);
     if (hit) trav_enter(t, sc.root_ref, entry);  // entry > 1e19 cannot happen
     else t.state = TRAV_DONE;
 }
