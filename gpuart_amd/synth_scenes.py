@@ -122,7 +122,7 @@ def write_ply(path, model, faces):
 
 
 def random_case(seed):
-    """A random parity case (tools/fuzz_parity.py, tests/golden `fuzz`): primitives of all four types incl. degenerate
+    """A random parity case (tests/fuzz_parity.py, tests/golden `fuzz`): primitives of all four types incl. degenerate
     ones (zero radii, zero-area and axis-aligned triangles, exact duplicates, cylinders), frame size, camera, user
     sphere, Sun, path depth, paths per pass. Everything is drawn from RandomState(seed) in a fixed order."""
     rs = np.random.RandomState(seed)

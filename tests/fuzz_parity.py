@@ -2,7 +2,7 @@
 """Randomised parity soak (GPU): random scenes of all four primitive types — including degenerate ones (zero radii,
 zero-area and axis-aligned triangles, duplicates, cones with equal radii, coincident coplanar faces) — random cameras,
 user-sphere modes, Sun on/off, path depths; direct lighting + a few path-tracing passes, compared bit for bit with the
-oracle.   python3 tools/fuzz_parity.py [first_seed] [count]"""
+oracle.   python3 tests/fuzz_parity.py [first_seed] [count]"""
 import ctypes as C
 import os
 import sys

@@ -2,7 +2,7 @@
 """Times the reference's unmodified GLSL on Mesa llvmpipe (container-only: needs /root/reference/shaders and
 oracle/_ref/libglref.so) on the bench workload, for the "reference GLSL path under llvmpipe" baseline of BASELINE.md.
 
-    python tools/time_llvmpipe.py [--width 1920 --height 1080 --passes 3 --scene scene_d|box]
+    python tests/golden/time_llvmpipe.py [--width 1920 --height 1080 --passes 3 --scene scene_d|box]
 Prints one JSON line: ms per path-tracing pass (1 path/pixel, MAX_PATH_SEGMENTS=8) and per direct-lighting frame, with the
 exact ray count of the same pass from the oracle's counters -> Mrays/s."""
 import argparse
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle", "glref"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

@@ -657,14 +657,14 @@ def test_full_size_frame_vs_reference_checksums(B, be, O, tag):
 
 
 def test_random_scenes_soak():
-    """tools/fuzz_parity.py: 60 random scenes of all four primitive types incl. degenerate ones (zero radii, zero-area
+    """tests/fuzz_parity.py: 60 random scenes of all four primitive types incl. degenerate ones (zero radii, zero-area
     and axis-aligned triangles, exact duplicates, cylinders), random cameras, user-sphere modes, Sun on/off, depths 1-8,
     1-2 paths per pass; direct lighting + 3 path-tracing passes in the wavefront and the megakernel mode, all bit for bit
     equal to the oracle (a 1 500-scene run of the same tool found no difference either)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "0", "60"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "0", "60"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60 scenes, 0 with differences" in r.stdout
 

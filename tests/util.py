@@ -63,7 +63,7 @@ def frame_golden_params(O, g):
 
 def fuzz_case_setup(O, seed):
     """(case, tree, camera, params, seeds) of random case `seed` (gpuart_amd.synth_scenes.random_case), as
-    tests/golden/make_golden.py `fuzz` and tools/fuzz_parity.py set it up."""
+    tests/golden/make_golden.py `fuzz` and tests/fuzz_parity.py set it up."""
     case = S.random_case(seed)
     cd = case["cam"]
     cam = O.camera(cd["pos"], cd["dir"], cd["up"], cd["fov_y"], cd["screen_dist"], case["W"], case["H"])
