@@ -169,3 +169,21 @@ def random_case(seed):
     return dict(prims=prims, W=W, H=H, cam=cam, us_flags=flags, user_sphere=us, us_em=3.0 if flags & 1 else 0.0,
                 sun_az=float(f32(rs.uniform(0, 6.28))), sun_alt=float(f32(rs.uniform(0.1, 1.5))), sun_on=bool(rs.rand() < 0.8),
                 max_segments=int(rs.choice([1, 3, 5, 8])), npaths=int(rs.choice([1, 1, 2])), passes=3)
+
+
+def random_wild_case(seed):
+    """random_case(seed) with hostile numbers: some primitive coordinates replaced by NaN, +-inf, +-1e30, +-1e-30 or -0
+    (tests/fuzz_parity.py --wild, tests/golden/soak_oracle_vs_reference.py --wild). The reference's comparisons decide what
+    such primitives do; the product must decide the same."""
+    case = random_case(seed)
+    rs = np.random.RandomState(1000003 + seed)
+    bad = [np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, -1e-30, -0.0, 0.0]
+    prims = []
+    for t, vals in case["prims"]:
+        vals = [f32(v) for v in vals]
+        if rs.rand() < 0.25:
+            for _ in range(int(rs.randint(1, 3))):
+                vals[int(rs.randint(len(vals)))] = f32(bad[int(rs.randint(len(bad)))])
+        prims.append((t, vals))
+    case["prims"] = prims
+    return case

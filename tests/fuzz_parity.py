@@ -17,13 +17,18 @@ from oracle import oracle as O  # noqa: E402
 f32 = np.float32
 
 
+WILD = "--wild" in sys.argv
+if WILD:
+    sys.argv.remove("--wild")
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     be = B.Backend(0)
     bad = 0
     for seed in range(first, first + count):
-        case = S.random_case(seed)
+        case = S.random_wild_case(seed) if WILD else S.random_case(seed)
         prims, W, H = case["prims"], case["W"], case["H"]
         cd = case["cam"]
         cam = O.camera(cd["pos"], cd["dir"], cd["up"], cd["fov_y"], cd["screen_dist"], W, H)

@@ -15,13 +15,18 @@ from oracle import oracle as O  # noqa: E402
 from oracle.glref import glref  # noqa: E402
 
 
+WILD = "--wild" in sys.argv
+if WILD:
+    sys.argv.remove("--wild")
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     gl = glref.GLRef()
     progs, bad = {}, 0
     for seed in range(first, first + count):
-        case = S.random_case(seed)
+        case = S.random_wild_case(seed) if WILD else S.random_case(seed)
         tree, _ = O.build_bvh(case["prims"])
         ms = case["max_segments"]
         if ms not in progs:
