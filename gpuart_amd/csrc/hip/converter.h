@@ -70,7 +70,10 @@ struct Converter {
 
     /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
     /// interior lower child's record directly follows its parent's); leaves append their primitives.
-    bool node(size_t addr, uint32_t depth, Child &out) {
+    /// `end` receives the address just past the subtree. Compile (reference src/bvh.cpp:161-222) lays subtrees out
+    /// contiguously in pre-order, so an upper child must start exactly where its sibling's subtree ends: this is
+    /// what rules out overlapping (DAG-shaped) inputs, whose conversion would otherwise take exponential time.
+    bool node(size_t addr, uint32_t depth, Child &out, size_t &end) {
         if (addr + 3 > nq) { err = "node address out of range"; return false; }
         if (depth > 1024) { err = "tree deeper than 1024 levels"; return false; }
         if (depth > max_depth) max_depth = depth;
@@ -102,6 +105,7 @@ struct Converter {
                 prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
             }
             out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS : 0u) | first;
+            end = a;
             return true;
         }
         uint32_t lo = bits(b[9]), hi = bits(b[10]);
@@ -111,8 +115,10 @@ struct Converter {
         if (r >= 0x3ffffff0u) { err = "too many nodes"; return false; }
         recs.resize(recs.size() + 4);
         Child L, H;
-        if (!node(lo, depth + 1, L)) return false;
-        if (!node(hi, depth + 1, H)) return false;
+        size_t lo_end = 0;
+        if (!node(lo, depth + 1, L, lo_end)) return false;
+        if (hi != lo_end) { err = "upper child does not start where the lower subtree ends"; return false; }
+        if (!node(hi, depth + 1, H, end)) return false;
         sanitize(L); sanitize(H);
         recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
         recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));

@@ -472,7 +472,8 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     Converter cv;
     cv.q = quads; cv.nq = nquads;
     Converter::Child root;
-    if (!cv.node(0, 0, root)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
+    size_t tree_end = 0;
+    if (!cv.node(0, 0, root, tree_end)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
     Converter::sanitize(root);
     int r;
     if ((r = gpuart_hip_flush(c))) return r;
@@ -555,9 +556,10 @@ int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
 /// Upper bound on the number of segments any path can have. colorWeight is multiplied per segment by the albedo
 /// of the primitive type that was hit (path_tracing.glsl:123-126,204) and the loop stops as soon as ANY channel
 /// is <= minWeight, so channel c survives at most as long as (largest albedo.c among the primitive types present
-/// in the scene)^n > minWeight; the bound is the smallest such n over the channels (+1 when a product comes
-/// within 1e-4 of minWeight, where fp32 rounding of a mixed product could differ). Kernels for segments beyond
-/// the bound would find empty queues; not launching them saves their fixed cost.
+/// in the scene)^n > minWeight; the bound is the smallest such n over the channels. The bound may only ever be too
+/// LARGE (a launch that finds an empty queue costs microseconds; a missing one would leave paths uncommitted), so the
+/// comparison is relaxed by 1e-4: fp32 products of mixed albedos can round differently from the powers taken here.
+/// k_shade additionally commits a path whose next segment would lie beyond the launched ones (belt and braces).
 static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
     if (p->maxSegments <= 0 || !(1.0f > p->minWeight)) return 0;
     uint32_t n = (uint32_t)p->maxSegments;
@@ -572,7 +574,7 @@ static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
         for (int t = 0; t < 4; t++) if (types & (1u << t)) a = std::max(a, ALBEDO[t][ch]);
         float w = 1.0f;
         uint32_t k = 0;
-        while (k < n && w > p->minWeight * 1.0001f) { w *= a; k++; }
+        while (k < n && w > p->minWeight * 0.9999f) { w *= a; k++; }
         bound = std::min(bound, k);
     }
     return std::max<uint32_t>(bound, 1);
@@ -620,8 +622,8 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seeds, j, npaths, b, l.passcolor);
         if (nseg && (r = trace(0, -1))) return r;
         for (uint32_t seg = 0; seg < nseg; seg++) {
-            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
-            else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, j, npaths, l.passcolor, c->d_counters);
+            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
+            else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
             // the Sun-shadow queries of this segment travel with the closest-hit queries of the next one
             const int next_c = seg + 1 < nseg ? (int)seg + 1 : -1, sh = p->sunEnabled == 1 ? (int)seg : -1;
             if ((next_c >= 0 || sh >= 0) && (r = trace(next_c, sh))) return r;
@@ -663,6 +665,7 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
     int r = check_ready(c, p);
     if (r) return r;
     if (!randSeed || npaths < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (p->maxSegments > GPUART_HIP_MAX_SEGMENTS) return fail(GPUART_HIP_ERR_ARG, "maxSegments exceeds GPUART_HIP_MAX_SEGMENTS");
     if (npaths == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     const float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);

@@ -269,7 +269,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
 // ---- wavefront stage 2: shade segment `seg` of every path in queue[seg&1] (path_tracing.glsl:182-233) ---
 template <bool REFWORK>
 __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int seg,
-                                                 int j, int npaths, float4 *accum, unsigned long long *gcounters) {
+                                                 int nseg, int j, int npaths, float4 *accum, unsigned long long *gcounters) {
     // Survivors are appended to the next queues through a per-wave staging list in LDS that is flushed with
     // ONE atomic per SHADE_ROUNDS*64 processed paths: a single atomic word sustains only ~90 appends/us on
     // MI355X, and one append per wave per 64 paths made this kernel atomic-bound.
@@ -300,7 +300,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
                 camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                 path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, seg, s.ush, s.specular, pathColor));
             } else {
-                go_on = s.next == PATH_CONTINUES;
+                // `seg + 1 < nseg` can only fail if the host's segment bound were too small: such a path is committed
+                // here instead of being queued for a launch that will not come (it would keep a stale colour)
+                go_on = s.next == PATH_CONTINUES && seg + 1 < nseg;
                 shadow = s.want_shadow && (REFWORK || s.sun_matters);
                 if (shadow)
                     b.sun[slot] = make_float4(s.sun_term.x, s.sun_term.y, s.sun_term.z, __uint_as_float(go_on ? 0u : 1u));

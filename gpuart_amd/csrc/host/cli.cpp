@@ -102,7 +102,12 @@ int main(int argc, char **argv) {
         ok = r.ReadDirectLighting(img.data());
     } else {
         r.RestartPathTracing(perPass, spp);
-        if (!resume.empty() && !r.LoadCheckpoint(resume.c_str())) return 1;
+        if (!resume.empty()) {
+            if (!r.LoadCheckpoint(resume.c_str())) return 1;
+            // the checkpoint restores the run's own target (normally already reached); the command line's --spp /
+            // --per-pass say how far to go on from there
+            r.ExtendPathTracing(perPass, spp);
+        }
         // the reference's draw loop: one pass per frame until pathsPerPixel is reached (src/main.cpp:554-582)
         while ((done = r.RenderPathTracingPass()) < r.GetPathsPerPixel()) passes++;
         passes++;

@@ -206,6 +206,15 @@ void Renderer::RestartPathTracing(unsigned pathsPerPass, unsigned pathsPerPixel)
     ResetPathTracing();
 }
 
+void Renderer::ExtendPathTracing(unsigned pathsPerPass, unsigned pathsPerPixel) {
+    PathTracing.pathsPerPixel = std::max(pathsPerPixel, PathTracing.numPathsRendered);
+    PathTracing.pathsPerPass = std::max(1u, std::min(pathsPerPass, PathTracing.pathsPerPixel));
+    if (Backend && Viewport.width) {
+        const unsigned left = PathTracing.pathsPerPixel - PathTracing.numPathsRendered;
+        gpuart_hip_pt_plan(Backend, (left + PathTracing.pathsPerPass - 1) / PathTracing.pathsPerPass);
+    }
+}
+
 unsigned Renderer::RenderPathTracingPass() {
     if (!IsOK) return PathTracing.numPathsRendered;
     if (PathTracing.numPathsRendered < PathTracing.pathsPerPixel) {

@@ -98,6 +98,9 @@ public:
     /// scene, camera, lighting and viewport/tile must have been set up as they were when saving.
     bool SaveCheckpoint(const char *fileName);
     bool LoadCheckpoint(const char *fileName);
+    /// Continues the current accumulation towards a new target without clearing it (RestartPathTracing would): used
+    /// after LoadCheckpoint to render on to more paths per pixel than the checkpointed run asked for.
+    void ExtendPathTracing(unsigned pathsPerPass, unsigned pathsPerPixel);
     gpuart_hip_ctx *GetBackend() const { return Backend; }
     unsigned GetTileWidth() const { return Tile.w; }
     unsigned GetTileHeight() const { return Tile.h; }

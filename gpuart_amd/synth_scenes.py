@@ -22,9 +22,9 @@ USER_SPHERE = (-0.4, 0.0, 0.2, 0.0)
 
 
 def camera_dir(cam):
-    """Dir = (0,0,0.95) - Pos, in float32 like Vec3f (src/main.cpp:611)."""
+    """Dir = (0,0,0.95) - Pos, in float32 like Vec3f (src/main.cpp:611); cameras with a "target" look at it instead."""
     p = np.array(cam["pos"], np.float32)
-    return tuple((np.array([0, 0, 0.95], np.float32) - p).tolist())
+    return tuple((np.array(cam.get("target", (0, 0, 0.95)), np.float32) - p).tolist())
 
 
 def f32(x):
@@ -187,3 +187,102 @@ def random_wild_case(seed):
         prims.append((t, vals))
     case["prims"] = prims
     return case
+
+
+# ---- stand-ins for the reference's two primitive-list scenes (data/cluster_100k.dat, data/tree1_21k.dat are absent) ----
+# Written in the dialect Utils::LoadPrimitives reads (src/utils.cpp:136-203): `sphere x y z [r]` (r defaults to 4) and
+# `cone x1 y1 z1 x2 y2 z2 r1 r2` lines, `#` comments; loaded as InitCluster / InitTree do (src/scenes.cpp:69-103).
+CLUSTER_LOAD = dict(magnification=0.01, translation=(0.0, 0.0, 2.5))   # InitCluster, src/scenes.cpp:73
+TREE_LOAD = dict(magnification=0.3, translation=(0.0, 0.0, 0.0))       # InitTree, src/scenes.cpp:91
+FLOOR_DISC_CT = (DISC, [1, 0, 0, 0, 0, 1, 6])                          # both scenes add Disc((1,0,0),(0,0,1),6)
+
+
+def _g9(x):
+    return "%.9g" % float(np.float32(x))  # 9 significant digits identify a float32 uniquely
+
+
+def cluster_dat_lines(n=100_000, seed=7):
+    """A globular-cluster-like cloud of `n` spheres in model units (Plummer profile, core radius 40, cut at 200 so that
+    after x0.01 and the lift by 2.5 everything floats above the floor); 5 % of the lines give no radius (-> 4)."""
+    rs = np.random.RandomState(seed)
+    u = rs.uniform(1e-4, 1.0, n)
+    rad = np.minimum(40.0 / np.sqrt(u ** (-2.0 / 3.0) - 1.0 + 1e-12), 200.0)
+    d = rs.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = d * rad[:, None]
+    explicit = rs.uniform(size=n) < 0.95
+    r = rs.uniform(0.4, 1.6, n)
+    lines = ["# synthetic stand-in for cluster_100k.dat: %d spheres" % n]
+    for i in range(n):
+        s = "sphere %s %s %s" % (_g9(p[i, 0]), _g9(p[i, 1]), _g9(p[i, 2]))
+        if explicit[i]:
+            s += " " + _g9(r[i])
+        lines.append(s)
+    return lines
+
+
+def tree_dat_lines(depth=8, seed=11):
+    """A branching tree: every branch is a cone (tapering conical frustum) that spawns three thinner, shorter children;
+    tips carry sphere "leaves". depth 8 -> 9 841 cones + ~11 000 spheres (the reference's tree1_21k: 21k cones + spheres)."""
+    rs = np.random.RandomState(seed)
+    lines = ["# synthetic stand-in for tree1_21k.dat"]
+
+    def branch(base, direction, length, r0, level):
+        tip = base + direction * length
+        r1 = r0 * 0.7
+        lines.append("cone %s %s" % (" ".join(_g9(v) for v in np.concatenate([base, tip])), _g9(r0) + " " + _g9(r1)))
+        if level == depth:
+            for _ in range(int(rs.randint(1, 3))):
+                c = tip + rs.normal(size=3) * 0.05
+                lines.append("sphere %s %s" % (" ".join(_g9(v) for v in c), _g9(rs.uniform(0.03, 0.09))))
+            return
+        for _ in range(3):
+            nd = direction + rs.normal(size=3) * 0.55
+            nd[2] = abs(nd[2]) * 0.6 + 0.15
+            nd /= np.linalg.norm(nd)
+            branch(tip, nd, length * 0.72, r1, level + 1)
+
+    branch(np.zeros(3), np.array([0.0, 0.0, 1.0]), 2.2, 0.25, 0)
+    return lines
+
+
+def dat_descs(lines, magnification=1.0, translation=(0.0, 0.0, 0.0)):
+    """What Utils::LoadPrimitives makes of the lines: translation + magnification * v and magnification * r in float32."""
+    m = np.float32(magnification)
+    t = np.array(translation, np.float32)
+    out = []
+    for ln in lines:
+        tok = ln.split()
+        if not tok or tok[0].startswith("#"):
+            continue
+        v = [np.float32(float(x)) for x in tok[1:]]
+        if tok[0] == "sphere":
+            c = t + m * np.array(v[:3], np.float32)
+            r = m * (v[3] if len(v) > 3 else np.float32(4.0))
+            out.append((SPHERE, [float(c[0]), float(c[1]), float(c[2]), float(r)]))
+        elif tok[0] == "cone":
+            c1 = t + m * np.array(v[0:3], np.float32)
+            c2 = t + m * np.array(v[3:6], np.float32)
+            out.append((CONE, [float(x) for x in c1] + [float(x) for x in c2] + [float(m * v[6]), float(m * v[7])]))
+    return out
+
+
+def cluster_scene(n=100_000, seed=7):
+    """The primitive list InitCluster would hand to SetPrimitives for the synthetic cluster file."""
+    return dat_descs(cluster_dat_lines(n, seed), **CLUSTER_LOAD) + [FLOOR_DISC_CT]
+
+
+def tree_scene(depth=8, seed=11):
+    """The primitive list InitTree would hand to SetPrimitives for the synthetic tree file."""
+    return dat_descs(tree_dat_lines(depth, seed), **TREE_LOAD) + [FLOOR_DISC_CT]
+
+
+def write_lines(path, lines):
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+# A second camera for the cluster / tree scenes: above the floor, close to the crown / the cluster's core (the default
+# camera sees both from 3 m away, mostly floor and sky).
+CLUSTER_NEAR_CAMERA = dict(pos=(0.3, -2.6, 1.7), target=(0.0, 0.0, 2.3), up=(0.0, 0.0, 1.0), dir=None, fov_y=60.0, screen_dist=0.2)
+TREE_NEAR_CAMERA = dict(pos=(0.6, -1.9, 1.9), target=(0.0, 0.0, 1.5), up=(0.0, 0.0, 1.0), dir=None, fov_y=60.0, screen_dist=0.2)
+NEAR_CAMERAS = {"cluster": CLUSTER_NEAR_CAMERA, "tree": TREE_NEAR_CAMERA}

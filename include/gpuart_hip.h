@@ -46,9 +46,11 @@ typedef struct gpuart_params {
     uint32_t userSphereFlags; /* UserSphereFlags: 1 = EM_NONZERO, 2 = SPECULAR, 4 = FUZZY */
     float pixelSize;          /* PixelSize */
     float cameraPos[3];       /* CameraPos */
-    int32_t maxSegments;      /* MAX_PATH_SEGMENTS, a shader const (5) in the reference */
+    int32_t maxSegments;      /* MAX_PATH_SEGMENTS, a shader const (5) in the reference; at most GPUART_HIP_MAX_SEGMENTS */
     float minWeight;          /* MIN_WEIGHT, a shader const (0.01) in the reference */
 } gpuart_params;
+
+#define GPUART_HIP_MAX_SEGMENTS 1024 /* gpuart_hip_pt_pass rejects larger maxSegments (one launch + counters per segment) */
 
 /* Exact work counters (closest-hit queries as the reference performs them). */
 typedef struct gpuart_counters {

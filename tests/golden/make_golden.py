@@ -350,7 +350,7 @@ class RefRenderer:
 
 
 def scene_tree(name):
-    prims = {"box": S.box_scene, "scene_p": S.scene_p, "scene_d": S.scene_d,
+    prims = {"box": S.box_scene, "scene_p": S.scene_p, "scene_d": S.scene_d, "cluster": S.cluster_scene, "tree": S.tree_scene,
              "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64)}[name]()
     tree, depth = O.build_bvh(prims)
     return prims, tree, depth
@@ -490,7 +490,45 @@ def gen_fullsize(gl):
             gl.L.glref_delete_tex(t)
 
 
-SECTIONS = dict(hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
+def gen_scene_p(gl):
+    """BASELINE cfg1 and cfg2 on Scene P (floor disc + 256 spheres + 16 tilted discs), default camera:
+    cfg1 = 256x256 direct lighting, the whole frame as bit patterns (+ two depth-4 path-tracing passes at that size);
+    cfg2 = 1920x1080 path tracing depth 4, 1 path/pixel/pass: direct lighting + two passes as per-row checksums."""
+    _, tree, _ = scene_tree("scene_p")
+    seeds = O.randseeds(16)
+    progs = RefPrograms(gl, 4)
+    r = RefRenderer(gl, progs, 256, 256, default_cam(), tree)
+    out = {"direct": r.direct()[..., :3].copy()}
+    r.reset()
+    out["pt_pass1"] = r.pt_pass(1, seeds[0])[..., :3].copy()
+    out["pt_acc"] = r.pt_pass(1, seeds[1])[..., :3].copy()
+    save("frames_scene_p_seg4", scene="scene_p", W=256, H=256, cam=r.cam, max_segments=4, npasses=2, seeds=seeds, **out)
+    r = RefRenderer(gl, progs, 1920, 1080, default_cam(), tree)
+    out = {"direct": row_checksums(r.direct())}
+    r.reset()
+    for k in range(2):
+        out["pt_acc%d" % (k + 1)] = row_checksums(r.pt_pass(1, seeds[k]))
+    save("fullsize_scene_p_1080p", W=1920, H=1080, cam=r.cam, max_segments=4, seeds=seeds[:2], npasses=2, **out)
+
+
+def gen_cluster_tree(gl):
+    """The reference's two primitive-list scenes (InitCluster: 100k spheres, InitTree: cones + spheres; src/scenes.cpp:69-103)
+    on seeded synthetic stand-ins of the absent data files: direct lighting + two path-tracing passes, 128x72, both cameras."""
+    seeds = O.randseeds(16)
+    progs = RefPrograms(gl)
+    for name in ("cluster", "tree"):
+        _, tree, depth = scene_tree(name)
+        for tag, camsel in (("", S.DEFAULT_CAMERA), ("_near", S.NEAR_CAMERAS[name])):
+            r = RefRenderer(gl, progs, 128, 72, default_cam(camsel), tree)
+            out = {"direct": r.direct()[..., :3].copy()}
+            r.reset()
+            out["pt_pass1"] = r.pt_pass(1, seeds[0])[..., :3].copy()
+            out["pt_acc"] = r.pt_pass(1, seeds[1])[..., :3].copy()
+            save("frames_%s%s_seg5" % (name, tag), scene=name, W=128, H=72, cam=r.cam, max_segments=5, npasses=2, seeds=seeds,
+                 bvh_depth=depth, **out)
+
+
+SECTIONS = dict(scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
                 disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 

@@ -302,6 +302,58 @@ def test_segment_and_weight_limits(B, be, O):
         be.set_mode(0)
 
 
+def test_segment_bound_next_to_albedo_powers(B, be, O):
+    """minWeight just below a power of an albedo (shaders/path_tracing.glsl:138-139,177: the loop continues while every
+    channel of colorWeight is > MIN_WEIGHT): the host's bound on the number of segment launches must not cut the segment
+    the reference still runs. An all-sphere pit (every bounce multiplies by the sphere albedo, so colorWeight.z is exactly
+    0.35^k) and Scene P, maxSegments 8, wavefront pipeline and megakernel against the oracle."""
+    a = np.float32(0.35); b = np.float32(0.4)
+    p4 = a * a * a * a
+    p5 = b * b * b * b * b
+    weights = [float(np.nextafter(p4, np.float32(0))), float(p4 / np.float32(1.00005)), float(np.nextafter(p5, np.float32(0))),
+               float(p4), float(np.nextafter(a * a, np.float32(0)))]
+    rng = np.random.RandomState(4)
+    pit = [(S.SPHERE, [0.0, 0.0, -100.0, 100.0])] + [
+        (S.SPHERE, [float(np.float32(x)), float(np.float32(y)), 0.25, 0.3]) for x, y in rng.uniform(-1.2, 1.2, (40, 2))]
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    W, H = 64, 40
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    deep = 0
+    for prims in (pit, S.scene_p()):
+        tree, _ = O.build_bvh(prims)
+        be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+        for mw in weights:
+            P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 8, mw)
+            acc = np.zeros((H, W, 4), np.float32)
+            st = O.pt_pass(tree, c, W, H, P, [0.3, 0.6, 0.9, 0.1], 2, acc)
+            deep += st.segments
+            for mode in (0, 2):
+                be.set_mode(mode)
+                be.pt_reset()
+                be.pt_pass(to_params(B, P), [0.3, 0.6, 0.9, 0.1], 2)
+                assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "minWeight=%.9g mode %d" % (mw, mode))
+            be.set_mode(0)
+    assert deep > 0
+
+
+def test_segment_budget_is_capped(B, be, O):
+    """maxSegments beyond GPUART_HIP_MAX_SEGMENTS (1024) is refused instead of allocating counters for 1e9 launches."""
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], 32, 16)
+    tree, _ = O.build_bvh(scene("box"))
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    be.resize(32, 16); be.upload_bvh(tree); be.set_camera(c)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 10 ** 9, 0.0)
+    with pytest.raises(B.HipError):
+        be.pt_pass(to_params(B, P), [0.3, 0.6, 0.9, 0.1], 1)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 1024, 0.0)
+    be.pt_reset(); be.pt_pass(to_params(B, P), [0.3, 0.6, 0.9, 0.1], 1)
+    acc = np.zeros((16, 32, 4), np.float32)
+    O.pt_pass(tree, c, 32, 16, P, [0.3, 0.6, 0.9, 0.1], 1, acc)
+    assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "maxSegments 1024, minWeight 0")
+
+
 def test_renderer_api_box_scene(B):
     """The C++ gpuart::Renderer driven like the reference app drives it (src/main.cpp:609-623,549-599)."""
     g = golden("frames_box_seg5")
@@ -423,6 +475,13 @@ def test_malformed_tree_is_rejected(B, be):
         be.upload_bvh(bad)
     with pytest.raises(B.HipError):
         be.upload_bvh(tree[:2])
+    # an upper child that points back into its sibling's subtree (a DAG): rejected, not converted in exponential time
+    dag = tree.copy()
+    u = dag.view(np.uint32)
+    assert u[2, 0] & 0x80000000 == 0 and u[2, 2] > 6   # the root is an interior node
+    u[2, 2] = 6                                        # its upper child := an address inside the lower subtree
+    with pytest.raises(B.HipError):
+        be.upload_bvh(dag)
     be.upload_bvh(tree)
 
 
@@ -636,14 +695,17 @@ def test_random_cases_vs_reference_goldens(B, be, O):
         be.set_mode(0)
 
 
-@pytest.mark.parametrize("tag", ["1080p", "4k"])
-def test_full_size_frame_vs_reference_checksums(B, be, O, tag):
+@pytest.mark.parametrize("sc,tag", [("scene_d", "1080p"), ("scene_d", "4k"), ("scene_p", "1080p")])
+def test_full_size_frame_vs_reference_checksums(B, be, O, sc, tag):
     """BASELINE cfg3 at FULL size as rendered by the reference's shaders on llvmpipe (per-row checksums of the float bit
     patterns, tests/golden/fullsize_scene_d_1080p.npz): the HIP path's direct-lighting frame and its accumulator after
-    one and two passes give the same checksums — full-size parity against the reference itself, not only the oracle."""
-    g = golden("fullsize_scene_d_" + tag)
+    one and two passes give the same checksums — full-size parity against the reference itself, not only the oracle.
+    ("scene_p", "1080p") is BASELINE cfg2: Scene P (256 spheres + 16 discs), depth 4, default camera — the generic
+    (all primitive types) BVH-query kernels at a BASELINE size; cfg1 (256x256 direct lighting, whole frame as bits) is
+    frames_scene_p_seg4 in test_frames_vs_reference_goldens."""
+    g = golden("fullsize_%s_%s" % (sc, tag))
     W, H = int(g["W"]), int(g["H"])
-    tree, _ = O.build_bvh(scene("scene_d"))
+    tree, _ = O.build_bvh(scene(sc))
     cam = g["cam"]
     sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
     P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], int(g["max_segments"]), 0.01)
@@ -739,3 +801,16 @@ def test_headless_cli(B, O, tmp_path):
         O.pt_pass(tree, c, W, H, P, seed, 2, acc)
     assert_bits(img.reshape(-1, 3), (acc[..., :3] / np.float32(4)).reshape(-1, 3), "CLI PFM vs oracle")
     assert open(ppm, "rb").read().startswith(b"P6\n%d %d\n255\n" % (W, H))
+
+
+def test_headless_cli_resume_continues_to_more_paths(tmp_path):
+    """gpuart_cli --resume: 4 spp with --checkpoint, then --resume ... --spp 8 == a straight 8-spp run, bit for bit."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpuart_amd", "bin", "gpuart_cli")
+    base = [exe, "--scene", "box", "--width", "72", "--height", "40", "--mode", "pt"]
+    ck, a, b = str(tmp_path / "r.ck"), str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+    for args in (["--spp", "4", "--checkpoint", ck], ["--resume", ck, "--spp", "8", "--pfm", a], ["--spp", "8", "--pfm", b]):
+        out = subprocess.run(base + args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+    assert '"paths_per_pixel": 8' in out.stdout
+    assert open(a, "rb").read() == open(b, "rb").read()

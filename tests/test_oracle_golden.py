@@ -179,14 +179,15 @@ def test_random_cases_vs_reference():
         assert_bits(acc[..., :3].reshape(-1, 3), g["pt_acc_%d" % seed].reshape(-1, 3), "case %d path tracing" % seed)
 
 
-@pytest.mark.parametrize("tag", ["1080p", "4k"])
-def test_full_size_frame_vs_reference_checksums(tag):
+@pytest.mark.parametrize("sc,tag", [("scene_d", "1080p"), ("scene_d", "4k"), ("scene_p", "1080p")])
+def test_full_size_frame_vs_reference_checksums(sc, tag):
     """BASELINE cfg3 at FULL size (Scene D, 1920x1080, depth 8, benchmark camera) as rendered by the reference's shaders
     on llvmpipe, held as per-row checksums of the float bit patterns: the oracle's direct-lighting frame and its
-    accumulator after one and two path-tracing passes give the same 3 x 1080 x 3 checksums."""
-    g = golden("fullsize_scene_d_" + tag)
+    accumulator after one and two path-tracing passes give the same 3 x 1080 x 3 checksums. ("scene_p", "1080p") is BASELINE
+    cfg2: Scene P (256 spheres + 16 discs), depth 4, default camera."""
+    g = golden("fullsize_%s_%s" % (sc, tag))
     W, H = int(g["W"]), int(g["H"])
-    tree, _ = O.build_bvh(scene("scene_d"))
+    tree, _ = O.build_bvh(scene(sc))
     cam = g["cam"]
     sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
     P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], int(g["max_segments"]), 0.01)

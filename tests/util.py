@@ -23,6 +23,8 @@ SCENES = {
     "box": S.box_scene,
     "scene_p": S.scene_p,
     "scene_d": S.scene_d,
+    "cluster": S.cluster_scene,
+    "tree": S.tree_scene,
     "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64),
 }
 

@@ -1,0 +1,213 @@
+// ubench.hip — micro-benchmarks that calibrate the ceilings the BVH-query kernel is priced against (gfx950 only):
+//   valu      : wave64 VALU issue rate per SIMD at 1..8 resident waves (independent / dependent v_fma_f32,
+//               and the v_cmp -> v_cndmask / v_med3 mix of the AABB test)
+//   aabb      : gd::aabb_entry (the product's own box test) on register-resident data: box tests per second with no memory
+//   gather    : 64-byte node records fetched at data-dependent addresses (4 x global_load_dwordx4 per lane), the access
+//               pattern of trav_step_box, over arrays of several sizes (L1 / L2 / Infinity-Cache resident)
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../../gpuart_amd/csrc/hip -I../../include -o ubench ubench.hip
+// Prints one line per measurement; `ubench json` prints one JSON object (tools/ubench/run.sh stores it under profiles/).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static int g_cus = 256;
+static double g_clock_hz = 2.4e9;
+
+// ---- VALU issue ---------------------------------------------------------------------------------
+// 16 independent accumulators, ITER x 16 v_fma_f32 per lane
+__global__ void __launch_bounds__(64) k_valu_indep(float *out, int iters, unsigned long long *cycles) {
+    float a[16];
+    for (int i = 0; i < 16; i++) a[i] = threadIdx.x * 0.001f + i;
+    float b = 1.0000001f, c = 1e-9f;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int i = 0; i < 16; i++) s += a[i];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+__global__ void __launch_bounds__(64) k_valu_dep(float *out, int iters, unsigned long long *cycles) {
+    float a = threadIdx.x * 0.001f;
+    float b = 1.0000001f, c = 1e-9f;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = a;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+// the select mix of the box test: k>=0 ? k : inf ; med3(v,lo,hi)==v ? c : inf  (4 independent chains, 16 VALU per round)
+__global__ void __launch_bounds__(64) k_valu_select(float *out, int iters, unsigned long long *cycles) {
+    float k[4], v[4];
+    for (int i = 0; i < 4; i++) { k[i] = threadIdx.x * 0.01f - 0.3f + i; v[i] = 0.5f + 0.001f * threadIdx.x; }
+    const float lo = 0.25f, hi = 0.75f, INF = __builtin_inff();
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float c = (k[i] >= 0) ? k[i] : INF;                                   // v_cmp + v_cndmask
+            c = (__builtin_amdgcn_fmed3f(v[i], lo, hi) == v[i]) ? c : INF;        // v_med3 + v_cmp + v_cndmask
+            asm volatile("" : "+v"(c));
+            k[i] = c * 0.999f;                                                    // v_mul
+            v[i] = v[i] + 1e-7f;                                                  // v_add
+            asm volatile("" : "+v"(k[i]), "+v"(v[i]));
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = k[0] + k[1] + k[2] + k[3] + v[0] + v[1] + v[2] + v[3];
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// ---- the product's box test on registers ---------------------------------------------------------
+__global__ void __launch_bounds__(64) k_aabb(float *out, int iters, unsigned long long *cycles) {
+    using namespace gd;
+    Ray r;
+    r.o = f3(0.1f + threadIdx.x * 0.01f, -3.0f, 1.0f);
+    r.d = f3(0.02f * threadIdx.x - 0.6f, 1.0f, -0.1f);
+    F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    F3 bmin = f3(-1, -1, 0), bmax = f3(1, 1, 2);
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        float e;
+        bool h = aabb_entry(r, rdiv, bmin, bmax, e);
+        acc += h ? e : 1.0f;
+        // keep the compiler from hoisting or simplifying any part of the test: every operand is opaque per iteration
+        asm volatile("" : "+v"(bmin.x), "+v"(bmin.y), "+v"(bmin.z), "+v"(bmax.x), "+v"(bmax.y), "+v"(bmax.z), "+v"(acc));
+        asm volatile("" : "+v"(r.o.x), "+v"(r.o.y), "+v"(r.o.z), "+v"(r.d.x), "+v"(r.d.y), "+v"(r.d.z));
+        asm volatile("" : "+v"(rdiv.x), "+v"(rdiv.y), "+v"(rdiv.z));
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// ---- gather of 64-byte records -------------------------------------------------------------------
+// chain: the next record index depends on the loaded data (as a traversal step's does); CHAINS independent chains per lane
+template <int CHAINS>
+__global__ void __launch_bounds__(64) k_gather(const float4 *__restrict__ recs, uint32_t mask, int iters, float *out,
+                                               unsigned long long *cycles) {
+    uint32_t idx[CHAINS];
+    float acc = 0;
+    for (int c = 0; c < CHAINS; c++) idx[c] = (blockIdx.x * 64 + threadIdx.x) * 2654435761u + c * 40503u;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) {
+            const float4 *rec = recs + 4 * (size_t)(idx[c] & mask);
+            float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            asm volatile("" : "+v"(q0.w), "+v"(q1.w));
+            acc += (q0.x + q1.y) + (q2.z + q3.x);
+            idx[c] = idx[c] * 1664525u + 1013904223u + __float_as_uint(q0.w) + __float_as_uint(q1.w);
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx[0];
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+struct Result { std::string name; double value; std::string unit; std::string note; };
+static std::vector<Result> g_results;
+
+template <class F>
+static void timed(const char *name, int waves_per_simd, double work_per_wave, const char *unit, F launch, const char *note = "") {
+    const int waves = g_cus * 4 * waves_per_simd;
+    float *out; unsigned long long *cyc;
+    CHECK(hipMalloc(&out, (size_t)waves * 64 * 4));
+    CHECK(hipMalloc(&cyc, (size_t)waves * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    launch(waves, out, cyc);  // warm-up
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    launch(waves, out, cyc);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(waves);
+    CHECK(hipMemcpy(h.data(), cyc, (size_t)waves * 8, hipMemcpyDeviceToHost));
+    double mean = 0;
+    for (auto v : h) mean += (double)v;
+    mean /= waves;
+    const double total = work_per_wave * waves;
+    const double rate = total / (ms * 1e-3);
+    // per-SIMD cycles per unit of work, from the wall time and the nominal clock; and from the in-kernel counter
+    const double cyc_wall = g_clock_hz * (ms * 1e-3) / (work_per_wave * waves_per_simd);
+    const double cyc_wave = mean / work_per_wave;  // s_memtime ticks per unit of work per wave
+    printf("%-34s waves/SIMD %d  %8.3f ms  %10.4g %s/s   %6.2f clk/unit/SIMD (wall @%.2f GHz)   %7.2f memtime-ticks/unit/wave  %s\n",
+           name, waves_per_simd, ms, rate, unit, cyc_wall, g_clock_hz / 1e9, cyc_wave, note);
+    char key[128];
+    snprintf(key, sizeof key, "%s.w%d", name, waves_per_simd);
+    g_results.push_back({key, rate, std::string(unit) + "/s", note});
+    snprintf(key, sizeof key, "%s.w%d.clk_per_unit_per_simd", name, waves_per_simd);
+    g_results.push_back({key, cyc_wall, "cycles", "wall time x nominal clock"});
+    CHECK(hipFree(out)); CHECK(hipFree(cyc));
+    CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+}
+
+int main(int argc, char **argv) {
+    const bool json = argc > 1 && !strcmp(argv[1], "json");
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    g_cus = prop.multiProcessorCount;
+    g_clock_hz = prop.clockRate * 1e3;
+    printf("device %s, %d CUs, clock %.0f MHz, wall-clock counter %d kHz\n", prop.gcnArchName, g_cus, prop.clockRate / 1e3, prop.clockRate);
+    const int iters = 4096;
+    for (int w : {1, 2, 4, 6, 8}) {
+        timed("valu_fma_independent", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_indep<<<n, 64>>>(o, iters, c); });
+    }
+    for (int w : {1, 2, 4, 6, 8}) {
+        timed("valu_fma_dependent", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_dep<<<n, 64>>>(o, iters, c); });
+    }
+    for (int w : {1, 2, 4, 6, 8}) {
+        timed("valu_select_mix", w, iters * 24.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_select<<<n, 64>>>(o, iters, c); },
+              "4 chains x (cmp, med3, cmp, cndmask, mul, add): 24 VALU + 6 SALU per round");
+    }
+    for (int w : {1, 2, 4, 6, 8}) {
+        timed("aabb_entry_registers", w, (double)iters, "box-tests(x64 lanes)", [&](int n, float *o, unsigned long long *c) { k_aabb<<<n, 64>>>(o, iters, c); });
+    }
+    // gather: arrays of 2^k records of 64 B
+    for (uint32_t log2n : {8u, 13u, 16u, 20u, 23u}) {  // 16 KB (L1), 512 KB (L2), 4 MB (one L2), 64 MB (Infinity Cache), 512 MB (HBM)
+        const size_t nrec = (size_t)1 << log2n;
+        float4 *recs;
+        CHECK(hipMalloc(&recs, nrec * 64));
+        std::vector<uint32_t> h(nrec * 16);
+        uint32_t s = 12345;
+        for (auto &v : h) { s = s * 1664525u + 1013904223u; v = s >> 3; }
+        CHECK(hipMemcpy(recs, h.data(), nrec * 64, hipMemcpyHostToDevice));
+        char name[64];
+        for (int w : {2, 6, 8}) {
+            snprintf(name, sizeof name, "gather64B_dep1_%zuKB", nrec * 64 / 1024);
+            timed(name, w, 512.0, "wave-gathers", [&](int n, float *o, unsigned long long *c) { k_gather<1><<<n, 64>>>(recs, (uint32_t)nrec - 1, 512, o, c); },
+                  "one dependent chain per lane");
+        }
+        for (int w : {6}) {
+            snprintf(name, sizeof name, "gather64B_dep4_%zuKB", nrec * 64 / 1024);
+            timed(name, w, 512.0 * 4, "wave-gathers", [&](int n, float *o, unsigned long long *c) { k_gather<4><<<n, 64>>>(recs, (uint32_t)nrec - 1, 512, o, c); },
+                  "four independent chains per lane");
+        }
+        CHECK(hipFree(recs));
+    }
+    if (json) {
+        printf("{");
+        for (size_t i = 0; i < g_results.size(); i++)
+            printf("%s\"%s\": %.6g", i ? ", " : "", g_results[i].name.c_str(), g_results[i].value);
+        printf("}\n");
+    }
+    return 0;
+}
