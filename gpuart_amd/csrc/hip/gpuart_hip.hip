@@ -16,6 +16,7 @@
 #include "gpuart_hip.h"
 
 #include "kernels_pipeline.h"
+#include "kernel_run.h"
 #include "kernels_test.h"
 #include "converter.h"
 
@@ -75,6 +76,7 @@ struct PassLane {
     float4 *passcolor = nullptr;   ///< colour per pass and pixel, added to the accumulator by k_accumulate
     uint4 *spill_main = nullptr;   ///< traversal-stack overflow of the lane's BVH-query launches
     uint32_t counter_segments = 0; ///< pb.counters holds 4*(counter_segments+1) words
+    uint32_t *run_cursor = nullptr;  ///< chunk cursor of the lane's k_run launch
     hipEvent_t ev_done = nullptr;  ///< the run has finished (main stream)
     hipEvent_t ev_free = nullptr;  ///< its colour has been accumulated (primary stream): the lane may be reused
     bool used = false;
@@ -95,6 +97,7 @@ struct gpuart_hip_ctx {
     uint32_t grid_waves = 4096;    ///< persistent grid: one wave per block
     uint32_t direct_waves = 4096;  ///< grid of k_direct_persistent (runs alone: needs the whole occupancy itself)
     uint32_t shade_waves = 4096;   ///< grid of the streaming kernels (k_gen, k_shade): latency-bound, so more waves than k_trace
+    uint32_t run_waves = 5120;     ///< grid of k_run: fills every SIMD by itself (5 waves per SIMD)
     TraceTuning tune{128, 16, 16, 3};
     uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
     uint32_t max_batch = 1;        ///< most passes one run of the pipeline may hold (batch_paths / tile slots, <= MAX_BATCH)
@@ -119,7 +122,10 @@ struct gpuart_hip_ctx {
     float4 *d_direct = nullptr, *d_accum = nullptr;
     size_t tile_pixels = 0;
     unsigned long long *d_counters = nullptr;
-    int mode = 0;  ///< 0 wavefront (fast), 1 reference-work (wavefront, full queries, counters), 2 megakernel
+    int mode = 0;  ///< gpuart_hip_set_mode: 0 fast (launch pipeline, or k_run for a small sequence), 1 reference work +
+                   ///< counters (k_run), 2 megakernel, 3 launch pipeline always, 4 fast with counters of the executed work
+                   ///< (k_run), 5 k_run always
+    size_t small_paths = (size_t)4 << 20;  ///< a pass sequence of at most this many paths goes through k_run in mode 0
     std::vector<TimedLaunch> pending, free_events;
     double timed_ms[2] = {0, 0};
     uint64_t timed_launches[2] = {0, 0};
@@ -153,7 +159,10 @@ void plan_runs(gpuart_hip_ctx *c) {
     const double unit = (double)((size_t)2 << 20);
     const size_t min_run = std::max<size_t>(1, c->min_run_paths / c->n_slots);
     size_t want;
-    if (c->planned_passes) {
+    if (c->planned_passes && (c->mode == 0 || c->mode == 5) && (size_t)c->planned_passes * c->n_slots <= c->small_paths &&
+        c->planned_passes <= c->max_batch) {
+        want = c->planned_passes;  // a small sequence is ONE run of the persistent kernel (uses_run_kernel)
+    } else if (c->planned_passes) {
         const double u = (double)c->planned_passes * c->n_slots / unit;
         want = (size_t)(c->plan_run_factor * std::sqrt(u) * unit / c->n_slots);
     } else {
@@ -245,7 +254,7 @@ int ensure_spill(gpuart_hip_ctx *c) {
     if (c->d_spill && c->spill_levels >= levels) return 0;
     int r = drain(c);
     if (r) return r;
-    const size_t bytes = ((size_t)levels + 1) * std::max(c->grid_waves, c->direct_waves) * BLOCK * sizeof(uint4);
+    const size_t bytes = ((size_t)levels + 1) * std::max({c->grid_waves, c->direct_waves, c->run_waves}) * BLOCK * sizeof(uint4);
     if (c->d_spill) { (void)hipFree(c->d_spill); c->d_spill = nullptr; }
     HIP_TRY(hipMalloc(&c->d_spill, bytes));
     for (auto &l : c->lanes) {
@@ -383,6 +392,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->grid_waves = c->num_cus * env_u32("GPUART_HIP_WAVES_PER_CU", 8, 1, 32);  // persistent grids of one-wave workgroups
     c->direct_waves = c->num_cus * env_u32("GPUART_HIP_DIRECT_WAVES_PER_CU", 16, 1, 32);
     c->shade_waves = c->num_cus * env_u32("GPUART_HIP_SHADE_WAVES_PER_CU", 24, 1, 64);
+    c->run_waves = c->num_cus * env_u32("GPUART_HIP_RUN_WAVES_PER_CU", 4 * GD_RUN_WAVES, 1, 32);
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 128, 16, 4096);
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
@@ -395,6 +405,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
     c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
+    c->small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 4096, 0, 1 << 20) << 10;
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -421,7 +432,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     for (auto &l : c->lanes) {
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.ev_free) (void)hipEventDestroy(l.ev_free);
-        void *lp[] = {l.pathmem, l.spill_main, l.pb.counters};
+        void *lp[] = {l.pathmem, l.spill_main, l.pb.counters, l.run_cursor};
         for (void *p : lp) if (p) (void)hipFree(p);
         if (l.main) (void)hipStreamDestroy(l.main);
     }
@@ -580,8 +591,58 @@ static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
     return std::max<uint32_t>(bound, 1);
 }
 
-/// Launches the collected passes as one run of the wavefront pipeline on the next pass lane.
 namespace {
+/// Whether a run of `count` passes goes through the persistent run kernel (k_run) rather than the launch pipeline.
+/// Measured on cfg3 (profiles/r02/k_run_vs_pipeline.txt): one pass alone 2.6 vs 3.4 ms, two 1.9 vs 2.0, four 1.66 vs 1.33,
+/// 64 1.02 vs 0.93 ms per pass — k_run has no chain of dependent launches, the pipeline packs lanes better once several
+/// runs overlap. Mode 0 therefore uses k_run when the whole planned sequence is small (an interactive frame).
+bool uses_run_kernel(const gpuart_hip_ctx *c, size_t count) {
+    if (c->mode == 1 || c->mode == 4 || c->mode == 5) return true;
+    if (c->mode != 0) return false;
+    const size_t passes = c->planned_passes ? c->planned_passes : count;
+    return passes * (size_t)c->n_slots <= c->small_paths;
+}
+
+/// The collected passes [first, first + count) as ONE persistent kernel per path of the pass (k_run, kernel_run.h) on
+/// pass lane `l`; then their colour planes are added to the accumulator in pass order on the primary stream.
+int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t count) {
+    int r;
+    const gpuart_params *p = &c->pend_params;
+    const int npaths = c->pend_npaths;
+    Scene sc = scene_of(c);
+    SeedBatch seeds{};
+    for (size_t k = 0; k < count; k++) seeds.seed[k] = c->pend_seeds[first + k];
+    if (!l.run_cursor) HIP_TRY(hipMalloc(&l.run_cursor, 64));
+    const PathBuffers &b = l.pb;
+    const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
+    const uint32_t chunks = b.n_slots * b.batch / BLOCK;
+    const dim3 grid(std::min<uint32_t>(c->run_waves, std::max<uint32_t>(1, chunks)));
+    TimedLaunch t;
+    if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous run has been accumulated
+    if ((r = begin_timed(c, t, 0, l.main))) return r;
+    for (int j = 0; j < npaths; j++) {
+        TimedLaunch tt;
+        HIP_TRY(hipMemsetAsync(l.run_cursor, 0, sizeof(uint32_t), l.main));
+        if (c->timing_level >= 2 && (r = begin_timed(c, tt, 1, l.main))) return r;
+        if (c->mode == 1) k_run<true, true, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->mode == 4 && flat_only) k_run<true, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->mode == 4) k_run<true, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (flat_only) k_run<false, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else k_run<false, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        HIP_TRY(hipGetLastError());
+        if (c->timing_level >= 2 && (r = end_timed(c, tt, l.main))) return r;
+    }
+    if ((r = end_timed(c, t, l.main))) return r;
+    HIP_TRY(hipEventRecord(l.ev_done, l.main));
+    HIP_TRY(hipStreamWaitEvent(c->stream, l.ev_done, 0));
+    k_accumulate<<<dim3((unsigned)((c->tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->tile_pixels, b.batch);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(l.ev_free, c->stream));
+    l.used = true;
+    return 0;
+}
+
+/// One run of the launch-per-stage wavefront pipeline (mode 3) for the pending passes [first, first + count).
 /// One run of the wavefront pipeline for the pending passes [first, first + count) on the next pass lane.
 int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     int r;
@@ -591,13 +652,13 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     TimedLaunch t;
     PassLane &l = c->lanes[c->next_lane];
     c->next_lane = (c->next_lane + 1) % c->lanes_in_use;
-    const uint32_t nseg = segment_bound(c, p);
     l.pb.batch = (uint32_t)count;
+    if (uses_run_kernel(c, count)) return launch_run_persistent(c, l, first, count);
+    const uint32_t nseg = segment_bound(c, p);
     SeedBatch seeds{};
     for (size_t k = 0; k < count; k++) seeds.seed[k] = c->pend_seeds[first + k];
     if ((r = ensure_segment_counters(c, l, nseg))) return r;
     const PathBuffers &b = l.pb;
-    const bool refwork = c->mode == 1;
     const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
@@ -610,8 +671,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         TimedLaunch tt;
         int rr;
         if (detail && (rr = begin_timed(c, tt, 1, l.main))) return rr;
-        if (refwork) k_trace<true, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 0, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-        else if (flat_only) k_trace<false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+        if (flat_only) k_trace<false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         else k_trace<false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         if (detail && (rr = end_timed(c, tt, l.main))) return rr;
         return 0;
@@ -622,8 +682,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seeds, j, npaths, b, l.passcolor);
         if (nseg && (r = trace(0, -1))) return r;
         for (uint32_t seg = 0; seg < nseg; seg++) {
-            if (refwork) k_shade<true><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
-            else k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
+            k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
             // the Sun-shadow queries of this segment travel with the closest-hit queries of the next one
             const int next_c = seg + 1 < nseg ? (int)seg + 1 : -1, sh = p->sunEnabled == 1 ? (int)seg : -1;
             if ((next_c >= 0 || sh >= 0) && (r = trace(next_c, sh))) return r;
@@ -649,7 +708,9 @@ int gpuart_hip_flush(gpuart_hip_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     // What is still pending when something observes or changes state (read-back, finish, ...) is split into runs of
     // at least ~2M paths on separate pass lanes, so that the end of a pass sequence still overlaps its kernels.
-    const size_t runs = std::max<size_t>(1, std::min<size_t>({(size_t)c->lanes_in_use, pending, pending * c->n_slots / c->min_run_paths}));
+    // (k_run fills the machine by itself: one run.)
+    const size_t runs = uses_run_kernel(c, pending) ? 1 :
+        std::max<size_t>(1, std::min<size_t>({(size_t)c->lanes_in_use, pending, pending * c->n_slots / c->min_run_paths}));
     int r = 0;
     for (size_t k = 0, first = 0; k < runs && !r; k++) {
         const size_t count = (pending - first) / (runs - k);
@@ -741,12 +802,13 @@ int gpuart_hip_finish(gpuart_hip_ctx *c) {
 }
 
 int gpuart_hip_set_mode(gpuart_hip_ctx *c, int mode) {
-    if (!c || mode < 0 || mode > 2) return fail(GPUART_HIP_ERR_ARG, "bad mode");
+    if (!c || mode < 0 || mode > 5) return fail(GPUART_HIP_ERR_ARG, "bad mode");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     int r = drain(c);  // modes use different streams; keep their passes ordered
     if (r) return r;
     c->mode = mode;
+    plan_runs(c);
     return 0;
 }
 

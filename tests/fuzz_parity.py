@@ -46,7 +46,7 @@ def main():
         gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
         be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
         res = {}
-        for mode in (0, 2):
+        for mode in (0, 2, 3):
             be.set_mode(mode)
             be.render_direct(gp); res["direct", mode] = be.read(0)
             be.pt_reset(); be.pt_plan(K)

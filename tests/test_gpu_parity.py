@@ -229,11 +229,13 @@ def test_frames_vs_reference_goldens(B, be, O, name):
         check_frame(be.read(1), g["pt_3paths"], "PT 3 paths/pass")
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("name", ["frames_box_seg5", "frames_scene_pc_seg5", "frames_scene_d_seg8", "frames_box_usph_fuzzy",
-                                  "frames_box_usph_em"])
+                                  "frames_box_usph_em", "frames_tree_near_seg5", "frames_scene_p_seg4"])
 def test_other_execution_modes_give_identical_frames(B, be, O, name, mode):
-    """reference-work pipeline (1) and megakernel (2) against the same goldens as the default pipeline."""
+    """Every execution mode against the same goldens as the default: 1 reference work (k_run, full queries, counters),
+    2 megakernel, 3 launch-per-stage wavefront pipeline, 4 executed-work counters (k_run), 5 persistent run kernel always
+    (mode 0 picks 3 or 5 by the size of the pass sequence)."""
     g = golden(name)
     W, H = int(g["W"]), int(g["H"])
     tree, _ = O.build_bvh(scene(str(g["scene"])))
@@ -605,8 +607,9 @@ def test_full_size_accumulation_is_additive(B, be, O, dragon_1080p):
     np.testing.assert_array_equal(d1, d2)
 
 
+@pytest.mark.parametrize("mode", [0, 3])
 @pytest.mark.parametrize("plan,npaths", [(0, 1), (7, 1), (70, 1), (1000, 1), (70, 3)])
-def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths):
+def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths, mode):
     """gpuart_hip_pt_pass only queues; passes travel through the pipeline in runs whose size follows the plan hint
     (gpuart_hip_pt_plan), the tile size and explicit flushes. Whatever the grouping — one pass at a time with a read-back
     after each, runs of up to 64 passes on a small tile, flushes in odd places, several paths per pass — the accumulator
@@ -620,6 +623,7 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths):
     K = 70 if npaths == 1 else 20
     seeds = O.randseeds(K)
     be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    be.set_mode(mode)  # 0: this small frame goes through the persistent run kernel; 3: the launch pipeline
     # one pass at a time, observed after each: the reference's own schedule
     be.pt_reset()
     for k in range(K):
@@ -634,6 +638,7 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths):
         if k in (3, 4, 40):
             be.flush()
     grouped = be.read(1)
+    be.set_mode(0)
     assert_bits(grouped.reshape(-1, 4), step_by_step.reshape(-1, 4), "grouped vs step by step, plan %d" % plan)
     if plan == 70:
         acc = np.zeros((H, W, 4), np.float32)
@@ -643,10 +648,13 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths):
 
 
 @pytest.mark.parametrize("env", [
-    {"GPUART_HIP_LANE_BUDGET_MB": "64", "GPUART_HIP_BATCH_MPATHS": "1"},
-    {"GPUART_HIP_PASSES_IN_FLIGHT": "1", "GPUART_HIP_MAX_BATCH": "3", "GPUART_HIP_LEAN_KERNELS": "0"},
+    {"GPUART_HIP_LANE_BUDGET_MB": "64", "GPUART_HIP_BATCH_MPATHS": "1", "GPUART_HIP_SMALL_KPATHS": "0"},
+    {"GPUART_HIP_PASSES_IN_FLIGHT": "1", "GPUART_HIP_MAX_BATCH": "3", "GPUART_HIP_LEAN_KERNELS": "0", "GPUART_HIP_SMALL_KPATHS": "0"},
     {"GPUART_HIP_WAVES_PER_CU": "1", "GPUART_HIP_CHUNK": "16", "GPUART_HIP_REFILL_LANES": "1", "GPUART_HIP_LEAF_LANES": "64",
-     "GPUART_HIP_PLAN_RUN_PERCENT": "10"},
+     "GPUART_HIP_PLAN_RUN_PERCENT": "10", "GPUART_HIP_SMALL_KPATHS": "0"},
+    # the persistent run kernel (what mode 0 picks for this small sequence): tiny grid, eager refills, generic kernels
+    {"GPUART_HIP_RUN_WAVES_PER_CU": "1", "GPUART_HIP_REFILL_LANES": "1", "GPUART_HIP_LEAN_KERNELS": "0", "GPUART_HIP_MAX_BATCH": "5"},
+    {"GPUART_HIP_RUN_WAVES_PER_CU": "32", "GPUART_HIP_REFILL_LANES": "64", "GPUART_HIP_LEAF_LANES": "1", "GPUART_HIP_LANE_BUDGET_MB": "64"},
 ])
 def test_scheduling_knobs_never_change_the_result(B, O, env, monkeypatch):
     """Memory budget, lanes in flight, run sizes, persistent-grid size, refill / leaf thresholds, kernel specialisation:
@@ -695,8 +703,9 @@ def test_random_cases_vs_reference_goldens(B, be, O):
         be.set_mode(0)
 
 
+@pytest.mark.parametrize("mode", [3, 5])
 @pytest.mark.parametrize("sc,tag", [("scene_d", "1080p"), ("scene_d", "4k"), ("scene_p", "1080p")])
-def test_full_size_frame_vs_reference_checksums(B, be, O, sc, tag):
+def test_full_size_frame_vs_reference_checksums(B, be, O, sc, tag, mode):
     """BASELINE cfg3 at FULL size as rendered by the reference's shaders on llvmpipe (per-row checksums of the float bit
     patterns, tests/golden/fullsize_scene_d_1080p.npz): the HIP path's direct-lighting frame and its accumulator after
     one and two passes give the same checksums — full-size parity against the reference itself, not only the oracle.
@@ -712,10 +721,14 @@ def test_full_size_frame_vs_reference_checksums(B, be, O, sc, tag):
     be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
     be.render_direct(to_params(B, P))
     np.testing.assert_array_equal(row_checksums(be.read(0)), g["direct"])
-    be.pt_reset()
-    for k in range(int(g["npasses"])):
-        be.pt_pass(to_params(B, P), g["seeds"][k], 1)
-        np.testing.assert_array_equal(row_checksums(be.read(1)), g["pt_acc%d" % (k + 1)])
+    be.set_mode(mode)  # both path-tracing pipelines at the BASELINE sizes: 3 launch pipeline, 5 persistent run kernel
+    try:
+        be.pt_reset()
+        for k in range(int(g["npasses"])):
+            be.pt_pass(to_params(B, P), g["seeds"][k], 1)
+            np.testing.assert_array_equal(row_checksums(be.read(1)), g["pt_acc%d" % (k + 1)])
+    finally:
+        be.set_mode(0)
 
 
 @pytest.mark.parametrize("wild", [False, True])

@@ -120,6 +120,41 @@ __global__ void __launch_bounds__(64) k_gather(const float4 *__restrict__ recs, 
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ---- how the vector-memory pipeline prices one wave-wide dwordx4 load, by address pattern ------------------------------
+// PATTERN 0: every lane its own random 64-B record, piece k in instruction k (what trav_step_box does: 64 distinct lines
+//            per instruction);  1: quad-cooperative — in instruction k the four lanes of a quad read the four 16-B pieces
+//            of the record wanted by the quad's k-th lane (16 distinct 64-B segments per instruction, same bytes in total);
+//            2: all 64 lanes consecutive 16-B pieces (1 KB contiguous);  3: all lanes the same 16 bytes;
+//            4: as 0 but only every 4th lane active (16 active lanes, 16 distinct lines)
+template <int PATTERN>
+__global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs, uint32_t mask, int iters, float *out,
+                                                 unsigned long long *cycles) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t idx = (blockIdx.x * 64 + lane) * 2654435761u;
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (PATTERN != 4 || (lane & 3) == 0)
+    for (int it = 0; it < iters; it++) {
+        float4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            size_t a;
+            if (PATTERN == 0 || PATTERN == 4) a = 4 * (size_t)(idx & mask) + k;
+            else if (PATTERN == 1) a = 4 * (size_t)((uint32_t)__shfl((int)idx, (int)((lane & ~3u) | k), 64) & mask) + (lane & 3);
+            else if (PATTERN == 2) a = 4 * (size_t)(((idx & mask) & ~63u)) + 64 * k + lane;  // wave-uniform base would be ideal; close enough
+            else a = 4 * (size_t)((uint32_t)__shfl((int)idx, 0, 64) & mask) + k;
+            q[k] = recs[a];
+        }
+        asm volatile("" : "+v"(q[0].w), "+v"(q[1].w), "+v"(q[2].w), "+v"(q[3].w));
+        acc += (q[0].x + q[1].y) + (q[2].z + q[3].x);
+        idx = idx * 1664525u + 1013904223u + __float_as_uint(q[0].w) + __float_as_uint(q[1].w) + __float_as_uint(q[2].w) + __float_as_uint(q[3].w);
+        if (PATTERN == 2) idx = (uint32_t)__shfl((int)idx, 0, 64);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 struct Result { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Result> g_results;
 
@@ -168,6 +203,13 @@ int main(int argc, char **argv) {
     g_clock_hz = prop.clockRate * 1e3;
     printf("device %s, %d CUs, clock %.0f MHz, wall-clock counter %d kHz\n", prop.gcnArchName, g_cus, prop.clockRate / 1e3, prop.clockRate);
     const int iters = 4096;
+    {   // bring the clocks up before anything is timed (the first kernels of a process run at idle clocks)
+        float *o; unsigned long long *cy;
+        CHECK(hipMalloc(&o, (size_t)g_cus * 32 * 64 * 4)); CHECK(hipMalloc(&cy, (size_t)g_cus * 32 * 8));
+        for (int r = 0; r < 40; r++) k_valu_indep<<<g_cus * 32, 64>>>(o, 8192, cy);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipFree(o)); CHECK(hipFree(cy));
+    }
     for (int w : {1, 2, 4, 6, 8}) {
         timed("valu_fma_independent", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_indep<<<n, 64>>>(o, iters, c); });
     }
@@ -182,7 +224,7 @@ int main(int argc, char **argv) {
         timed("aabb_entry_registers", w, (double)iters, "box-tests(x64 lanes)", [&](int n, float *o, unsigned long long *c) { k_aabb<<<n, 64>>>(o, iters, c); });
     }
     // gather: arrays of 2^k records of 64 B
-    for (uint32_t log2n : {8u, 13u, 16u, 20u, 23u}) {  // 16 KB (L1), 512 KB (L2), 4 MB (one L2), 64 MB (Infinity Cache), 512 MB (HBM)
+    for (uint32_t log2n : {8u, 16u, 20u}) {  // 16 KB (L1), 512 KB (L2), 4 MB (one L2), 64 MB (Infinity Cache), 512 MB (HBM)
         const size_t nrec = (size_t)1 << log2n;
         float4 *recs;
         CHECK(hipMalloc(&recs, nrec * 64));
@@ -200,6 +242,24 @@ int main(int argc, char **argv) {
             snprintf(name, sizeof name, "gather64B_dep4_%zuKB", nrec * 64 / 1024);
             timed(name, w, 512.0 * 4, "wave-gathers", [&](int n, float *o, unsigned long long *c) { k_gather<4><<<n, 64>>>(recs, (uint32_t)nrec - 1, 512, o, c); },
                   "four independent chains per lane");
+        }
+        CHECK(hipFree(recs));
+    }
+    {
+        const size_t nrec = (size_t)1 << 16;  // 4 MB
+        float4 *recs;
+        CHECK(hipMalloc(&recs, nrec * 64));
+        std::vector<uint32_t> h(nrec * 16);
+        uint32_t sd = 777;
+        for (auto &v : h) { sd = sd * 1664525u + 1013904223u; v = sd >> 3; }
+        CHECK(hipMemcpy(recs, h.data(), nrec * 64, hipMemcpyHostToDevice));
+        const uint32_t m = (uint32_t)nrec - 1;
+        for (int w : {2, 6}) {
+            timed("load4x16B_lane_divergent", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<0><<<n, 64>>>(recs, m, 1024, o, c); }, "64 lanes x own 64-B record");
+            timed("load4x16B_quad_cooperative", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<1><<<n, 64>>>(recs, m, 1024, o, c); }, "same bytes, a quad reads one record per instruction");
+            timed("load4x16B_contiguous", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<2><<<n, 64>>>(recs, m, 1024, o, c); }, "1 KB contiguous per instruction");
+            timed("load4x16B_broadcast", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<3><<<n, 64>>>(recs, m, 1024, o, c); }, "all lanes one record");
+            timed("load4x16B_16_lanes", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<4><<<n, 64>>>(recs, m, 1024, o, c); }, "16 active lanes, own records");
         }
         CHECK(hipFree(recs));
     }
