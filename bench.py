@@ -1,28 +1,43 @@
 #!/usr/bin/env python3
-"""bench.py — the hot path measured as BASELINE.json asks: Mrays/s (+ ms/frame) of progressive path
-tracing, dragon-class scene (Scene D: 100 352-triangle mesh + floor disc), 1920x1080, path depth 8,
-1 path per pixel per pass, on N GPUs of one node.
+"""bench.py — the hot path measured as BASELINE.json asks: Mrays/s (+ ms/frame) of progressive path tracing, dragon-class
+scene (Scene D: 100 352-triangle mesh + floor disc), 1920x1080, path depth 8, 1 path per pixel per pass, on N GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one process per GPU. Started by `python -m torch.distributed.run ... bench.py --gpus N ...` the ranks are
+        taken from the environment; started plainly, bench.py starts that launcher itself (before anything touches a GPU)
+        and relays rank 0's line — it never reports n_gpus != the ranks that rendered.
 
-A "step" is one progressive pass (gpuart::Renderer::RenderPathTracingPass) over the whole frame. With
-N>1 the FIXED 1080p frame is sharded by screen space across ranks (8-row bands dealt round-robin; strong
-scaling, north_star's "tile scaling"); after the K timed passes every rank exports its accumulated
-radiance and rank 0 gathers it over RCCL (inside the timed region).
+A "step" is one progressive pass (gpuart::Renderer::RenderPathTracingPass) over the whole frame. With N > 1 the FIXED frame
+is sharded by rows (8-row bands dealt round-robin, gpuart_hip_share_of_rank; strong scaling, north_star's "tile scaling");
+after the K timed passes every rank hands its normalised rows to the library's RCCL gather (gpuart_hip_gather, inside the
+timed region).
 
-Rays are counted exactly (closest-hit queries as the reference performs them: camera, bounce and Sun
-shadow rays) by running the same K passes once, untimed, in the library's reference-work mode; the
-timed run uses the default fast mode, whose images are bit-identical (tests/test_gpu_parity.py).
+What is counted:
+  * `value` = reference-defined rays / wall time: every closest-hit BVH query the REFERENCE performs for these K passes
+    (camera, bounce and Sun-shadow rays), counted exactly by the library's reference-work mode in an untimed
+    replay. The timed (fast) mode renders bit-identical images with less work — it skips Sun-shadow queries that cannot
+    matter and stops them at the first hit — so `rays_executed` (counted in a second untimed replay, mode 4) is reported
+    beside it, with its own rate.
+  * `roofline` is a device-level fraction: wave64 VALU instructions of all kernels of a pass (SQ_INSTS_VALU, collected by a
+    rocprofv3 child run of THIS invocation on the same passes) / ms_per_step, against the VALU issue peak. The HBM view
+    (algorithmic bytes, and the HBM traffic of the same child runs) is carried as secondary fields: the 8.7 MB tree is
+    cache-resident, so algorithmic bytes / time exceeds the HBM peak and is not a fraction of anything.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 # The renderer keeps up to 8 pipeline runs in flight on 9 HIP streams; with ROCm's default of 4 hardware queues their kernels would
-# serialise. Must be set before the HIP runtime initialises (i.e. before torch is imported). See DESIGN.md §4.
+# serialise. Must be set before the HIP runtime initialises (i.e. before torch is imported). See DESIGN.md section 4.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np
@@ -30,16 +45,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from gpuart_amd import binding as B  # noqa: E402
-from gpuart_amd import sharding  # noqa: E402
-from gpuart_amd import synth_scenes as S  # noqa: E402
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling";
+                                # measured on the box: profiles/r02/ubench.txt)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-W, H = 1920, 1080
-MAX_SEGMENTS = 8
+# The reference's own GLSL on Mesa llvmpipe, measured in the BUILD CONTAINER (8 vCPU; tests/golden/time_llvmpipe.py, output in
+# profiles/r02/llvmpipe_reference_glsl_container.txt). /root/reference cannot travel to the GPU box, so this is a recorded figure,
+# labelled as such; `cpu_baseline` is the figure measured in this run on this box.
+LLVMPIPE_CONTAINER = {
+    "cfg3": {"value": 0.957, "ms_per_frame": 5428.8},
+    "cfg2": {"value": 3.315, "ms_per_frame": 1409.3},
+}
+
+WORKLOADS = {
+    "cfg3": dict(text="Scene D (dragon-class, 100352 triangles + floor disc)", segs=8, camera="benchmark camera"),
+    "cfg2": dict(text="Scene P (256 spheres + 16 discs)", segs=4, camera="default camera"),
+    "cluster": dict(text="InitCluster on the synthetic cluster_100k stand-in (100000 spheres + floor disc)", segs=5, camera="near camera"),
+    "tree": dict(text="InitTree on the synthetic tree1_21k stand-in (9841 cones + 9775 spheres + floor disc)", segs=5, camera="near camera"),
+}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -47,27 +73,128 @@ def main():
     ap.add_argument("--frame", default="1920x1080",
                     help="frame size WxH (default: cfg3's 1080p, the configuration the metric is quoted on; 3840x2160 = "
                          "the 4K frame north_star also asks for — see DESIGN.md for its numbers)")
-    ap.add_argument("--workload", choices=["cfg3", "cfg2"], default="cfg3",
-                    help="cfg3 (default, the configuration the metric is quoted on): Scene D, depth 8; cfg2 of BASELINE.json: "
-                         "the primitives-only Scene P (spheres + discs), depth 4, default camera")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3",
+                    help="cfg3 (default, the configuration the metric is quoted on): Scene D, depth 8; cfg2 of BASELINE.json: Scene P, "
+                         "depth 4; cluster / tree: the reference's two primitive-list scenes (InitCluster / InitTree) on seeded stand-ins")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child runs (roofline counters become null)")
     ap.add_argument("--verify-gather", action="store_true",
                     help="rank 0 also renders the whole frame alone and checks the gathered frame against it bit for bit")
-    args = ap.parse_args()
-    global W, H, MAX_SEGMENTS
+    ap.add_argument("--render-only", action="store_true",
+                    help="(internal) render warm-up + steps passes of the workload and exit: the program the rocprofv3 child runs profile")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU ourselves (before any GPU call)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+def make_renderer(args, W, H, device, tmpdir):
+    """The workload's Renderer (gpuart::Renderer API; scene build is not part of the timed region) + what the oracle needs."""
+    from gpuart_amd import binding as B
+    from gpuart_amd import synth_scenes as S
+    w = args.workload
+    cam = dict({"cfg3": S.BENCH_CAMERA, "cfg2": S.DEFAULT_CAMERA, "cluster": S.CLUSTER_NEAR_CAMERA, "tree": S.TREE_NEAR_CAMERA}[w])
+    cam["dir"] = S.camera_dir(cam)
+    t0 = time.time()
+    r = B.Renderer(W, H, cam, device=device)
+    r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+    if w in ("cfg3", "cfg2"):
+        descs = S.scene_d() if w == "cfg3" else S.scene_p()
+        r.set_primitives(B.make_prims(descs))
+    else:  # through the reference's loader path: a .dat file, InitCluster / InitTree (src/scenes.cpp:69-103)
+        lines = S.cluster_dat_lines() if w == "cluster" else S.tree_dat_lines()
+        path = os.path.join(tmpdir, w + ".dat")
+        S.write_lines(path, lines)
+        assert (r.init_cluster(path) if w == "cluster" else r.init_tree(path)), "scene file did not load"
+        descs = S.dat_descs(lines, **(S.CLUSTER_LOAD if w == "cluster" else S.TREE_LOAD)) + [S.FLOOR_DISC_CT]
+    r.set_max_path_segments(WORKLOADS[w]["segs"])
+    assert r.is_ok()
+    return r, cam, descs, time.time() - t0
+
+
+def run_passes(r, n):
+    r.restart_path_tracing(1, n)
+    for _ in range(n):
+        r.path_tracing_pass()
+
+
+def profile_children(args, K, Wm):
+    """rocprofv3 child runs of `bench.py --render-only` (the same W + K passes): SQ_INSTS_VALU etc. in one --pmc pass, FETCH_SIZE and
+    WRITE_SIZE in one pass each (the TCC slots do not hold both, MI355X_MICROARCH.md "rocprofv3 PMC slots"). Counters are summed over
+    every dispatch of the child and divided by its W + K passes. Returns (dict, note)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--render-only", "--steps", str(K), "--warmup", str(Wm), "--workload", args.workload,
+             "--frame", args.frame]
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for tag, counters in (("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES"]),
+                          ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        d = tempfile.mkdtemp(prefix="gpuart_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc"] + counters + ["-d", d, "-o", "x", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(counters), p.returncode, (p.stderr or p.stdout)[-300:])
+            tot, per_kernel = {}, {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    v = float(row["Counter_Value"])
+                    tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + v
+                    if row["Counter_Name"] == "SQ_INSTS_VALU":
+                        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                        per_kernel[k] = per_kernel.get(k, 0.0) + v
+            out[tag] = (tot, per_kernel)
+        except Exception as e:  # noqa: BLE001
+            return None, "rocprofv3 child run failed: %r" % (e,)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out, "rocprofv3 --pmc child runs of this invocation (`%s`), sums over all dispatches / %d passes" % (" ".join(child[1:]), K + Wm)
+
+
+def main():
+    args = parse_args()
     W, H = (int(x) for x in args.frame.lower().split("x"))
-    cfg2 = args.workload == "cfg2"
-    scene_descs = S.scene_p() if cfg2 else S.scene_d()
-    if cfg2:
-        MAX_SEGMENTS = 4
+    K, Wm = args.steps, args.warmup
+    segs = WORKLOADS[args.workload]["segs"]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # does not return
+
+    from gpuart_amd import binding as B
+    from gpuart_amd import sharding
+    from gpuart_amd import synth_scenes as S
+    tmpdir = tempfile.mkdtemp(prefix="gpuart_bench_")
+
+    if args.render_only:  # the profiled child: same scene, same seeds, same pass sequence; nothing else
+        r, _, _, _ = make_renderer(args, W, H, 0, tmpdir)
+        r.set_seed(5489)
+        run_passes(r, Wm)
+        r.finish()
+        r.set_seed(5489)
+        run_passes(r, K)
+        r.finish()
+        r.close()
+        shutil.rmtree(tmpdir, ignore_errors=True)
+        return
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: the line would not describe the ranks that rendered" % (args.gpus, world))
     dist = None
-    # GPUART_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share GPUs,
-    # the exchange is staged through host memory); the driver's runs use RCCL ("nccl").
+    # GPUART_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share GPUs, the exchange is
+    # staged through host memory by sharding.gather_shares_host); the driver's runs use RCCL ("nccl").
     backend = os.environ.get("GPUART_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
@@ -77,65 +204,78 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", local_rank)
-    xdev = dev if backend == "nccl" else torch.device("cpu")  # where exchanged tensors live
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where tensors exchanged through torch.distributed live
     torch.cuda.set_device(dev)
 
-    # ---- scene + renderer (gpuart::Renderer API; scene build is not part of the timed region) ----
-    cam = dict(S.DEFAULT_CAMERA if cfg2 else S.BENCH_CAMERA)
-    cam["dir"] = S.camera_dir(cam)
-    t0 = time.time()
-    prims = B.make_prims(scene_descs)
-    r = B.Renderer(W, H, cam, device=local_rank)
-    r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
-    r.set_primitives(prims)
-    r.set_max_path_segments(MAX_SEGMENTS)
-    setup_s = time.time() - t0
+    r, cam, scene_descs, setup_s = make_renderer(args, W, H, local_rank, tmpdir)
     be = r.backend
     info = be.scene_info()
 
-    # ---- tile of this rank: 8-row bands of the frame dealt round-robin to the ranks (balances sky / floor / mesh
-    #      rows statistically; 8x8 pixel tiles stay intact); nothing is exchanged until the final gather ----
+    # ---- this rank's share: 8-row bands of the frame dealt round-robin to the ranks (balances sky / floor / mesh rows
+    #      statistically; 8x8 pixel tiles stay intact); nothing is exchanged until the final gather ----
+    share = B.share_of_rank(W, H, rank, world)
+    th = share.th
+    gather_note = None
     if world > 1:
-        y0, th, band, stride, my_rows = sharding.interleaved_rows(rank, world, H)
-        assert r.set_interleaved_tile(0, y0, W, th, band, stride)
-    else:
-        y0, th = 0, H
+        assert th > 0, "frame too small for %d ranks" % world
+        assert r.set_interleaved_tile(share.x0, share.y0, share.tw, share.th, share.band_rows, share.band_stride)
+        if backend == "nccl":
+            # the library's own communicator: rank 0's id travels through torch.distributed, then ncclCommInitRank per rank
+            idt = torch.zeros(128, dtype=torch.uint8, device=xdev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(B.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            try:
+                be.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+            except B.HipError as e:
+                gather_note = "gpuart_hip_comm_init failed (%s): gathered through torch.distributed point-to-point instead" % e
+        else:
+            gather_note = "GPUART_BENCH_BACKEND=%s rehearsal: gathered through host memory" % backend
 
-    K, Wm = args.steps, args.warmup
+    # ---- exact work counts: the same K passes, untimed; reference-defined (mode 1) and as the fast mode executes them (mode 4) ----
+    def count(mode):
+        r.set_seed(5489)
+        be.set_mode(mode)
+        be.counters(reset=True)
+        run_passes(r, K)
+        be.finish()
+        c = be.counters(reset=True)
+        be.set_mode(0)
+        return [c.rays, c.nodes, c.prim_tests[0], c.prim_tests[1], c.prim_tests[2], c.prim_tests[3], c.segments,
+                c.algorithmic_bytes() + 32 * W * th * K]
 
-    def run_passes(n):
-        r.restart_path_tracing(1, n)
-        for _ in range(n):
-            r.path_tracing_pass()
-
-    # ---- exact ray / algorithmic-byte counts: the same K passes, untimed, reference-work mode ----
-    r.set_seed(5489)
-    be.set_mode(1)
-    be.counters(reset=True)
-    run_passes(K)
-    be.finish()
-    cnt = be.counters(reset=True)
-    be.set_mode(0)
-    counts = torch.tensor([cnt.rays, cnt.nodes, cnt.prim_tests[0], cnt.prim_tests[1], cnt.prim_tests[2], cnt.prim_tests[3],
-                           cnt.segments, cnt.algorithmic_bytes() + 32 * W * th * K], dtype=torch.float64, device=xdev)
-    my_alg_bytes = float(counts[7])
+    counts = torch.tensor(count(1) + count(4), dtype=torch.float64, device=xdev)
     if dist is not None:
         dist.all_reduce(counts)
-    rays, nodes, segments, alg_bytes = float(counts[0]), float(counts[1]), float(counts[6]), float(counts[7])
+    ref, exe = counts[:8].tolist(), counts[8:].tolist()
+    rays, nodes, segments, alg_bytes = ref[0], ref[1], ref[6], ref[7]
 
     # ---- warm-up (untimed), then EXACTLY K timed passes ----
+    full = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    host_tile = None
+
+    def gather(divide_by):
+        """Every rank's normalised rows -> rank 0's `full` (device). The library's RCCL gather; the announced fallback otherwise."""
+        nonlocal host_tile
+        if gather_note is None:
+            be.gather(1, divide_by, 0, full.data_ptr() if rank == 0 else 0)
+            be.finish()
+            return
+        if host_tile is None:
+            host_tile = torch.empty((th, W, 4), dtype=torch.float32, device=dev)
+        be.export(1, host_tile.data_ptr(), divide_by)
+        be.finish()
+        fh = torch.empty((H, W, 4), dtype=torch.float32) if rank == 0 else None
+        sharding.gather_shares_host(_P2P(dist, xdev), host_tile.cpu(), rank, world, W, H, fh)
+        if rank == 0:
+            full.copy_(fh)
+
     r.set_seed(5489)
-    gather_buf = torch.empty((th, W, 4), dtype=torch.float32, device=dev)
-    full = torch.empty((H, W, 4), dtype=torch.float32, device=xdev) if (dist is not None and rank == 0) else None
-    run_passes(Wm)
+    run_passes(r, Wm)
     be.finish()
     if dist is not None:
-        # warm the exchange path too: the first point-to-point transfer between two ranks sets up their channel
-        be.export(1, gather_buf.data_ptr(), float(max(1, Wm)))
-        be.finish()
-        sharding.gather_interleaved(dist, gather_buf.to(xdev), rank, world, H, full)
+        gather(float(max(1, Wm)))  # warm the exchange path too: the first transfer between two ranks sets up their channel
     r.set_seed(5489)
     be.set_timing(2)
     be.kernel_time(0, reset=True)
@@ -144,12 +284,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_passes(K)
+    run_passes(r, K)
     if dist is not None:
-        # RCCL gather of the normalised radiance tiles to rank 0 (bands differ in height -> send/recv)
-        be.export(1, gather_buf.data_ptr(), float(K))
-        be.finish()
-        sharding.gather_interleaved(dist, gather_buf.to(xdev), rank, world, H, full)
+        gather(float(K))
     be.finish()
     torch.cuda.synchronize()
     if dist is not None:
@@ -157,6 +294,7 @@ def main():
     elapsed = time.perf_counter() - t0
     pass_ms, passes = be.kernel_time(0, reset=True)
     kernel_ms, launches = be.kernel_time(1, reset=True)
+    be.set_timing(1)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -170,34 +308,69 @@ def main():
     if args.verify_gather and dist is not None:
         assert r.set_tile(0, 0, W, H)
         r.set_seed(5489)
-        run_passes(K)
+        run_passes(r, K)
         whole = r.read_radiance(True)
         got = full.cpu().numpy()
         same = (got[..., :3].view(np.uint32) == whole[..., :3].view(np.uint32)).all()
         print("verify-gather: gathered %d interleaved row sets == single-rank frame: %s" % (world, bool(same)), file=sys.stderr)
         assert same, "gathered frame differs from the single-rank frame"
 
-    mrays = rays / elapsed / 1e6
-    # Dominant kernel = k_trace (all BVH queries: the closest-hit and Sun-shadow launches of the wavefront pipeline).
-    # HIP events around every launch (recorded on the launching stream, inside the timed region) give its average launch
-    # duration (it agrees with the rocprofv3 --kernel-trace average under profiles/). `achieved` = algorithmic bytes per
-    # launch / that average duration. Several pipeline runs are in flight at once, so launches OVERLAP and each sees only
-    # a share of the GPU: `concurrency` = sum of launch durations / wall time, and `achieved_aggregate` = all algorithmic
-    # bytes of the kernel's launches / wall time of the timed region (= achieved x concurrency). The tree is cache
-    # resident (see `traffic`), which is why the aggregate can exceed the HBM peak: the HBM roofline is the frame the
-    # survey prescribes for this path, not what limits it (VALU issue).
+    # ---- one pass alone, observed after it (the reference's interactive loop, src/main.cpp:549-599): frame time, not throughput ----
+    single_ms = None
+    if world == 1:
+        ts = []
+        for _ in range(7):
+            t1 = time.perf_counter()
+            run_passes(r, 1)
+            be.finish()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        single_ms = float(np.median(ts[2:]))
+
+    # ---- roofline: device-level VALU issue fraction (+ HBM views), counters from rocprofv3 child runs of this invocation ----
+    ms_step = elapsed / K * 1e3
     avg_kernel_ms = kernel_ms / max(1, launches)
-    concurrency = kernel_ms / (elapsed * 1e3)
-    bytes_per_launch = my_alg_bytes / max(1, launches)
-    achieved_per_launch = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
-    achieved_gbs = my_alg_bytes / elapsed / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s", "frac": None,
+            "traffic": None,
+            "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step (device level: overlapping launches are not double "
+                          "counted), against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+            "kernel": "k_trace (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
+            "kernel_avg_ms": round(avg_kernel_ms, 5), "kernel_launches": launches, "kernel_ms_summed_per_pass": round(kernel_ms / K, 4),
+            "kernel_concurrency": round(kernel_ms / (elapsed * 1e3), 3),
+            "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "algorithmic_bytes_per_pass_reference": alg_bytes / K, "algorithmic_bytes_per_pass_executed": exe[7] / K,
+                    "algorithmic_rate_executed": round(exe[7] / elapsed / 1e9, 1),
+                    "algorithmic_rate_over_peak": round(exe[7] / elapsed / 1e9 / HBM_PEAK_GBS, 3),
+                    "note": "algorithmic bytes (SURVEY.md 8(d): 48 B per node tested + 32/48/64/80 B per primitive tested + 32 B per pixel "
+                            "and pass) / wall time. Above the HBM peak because the tree is cache-resident (L2 / Infinity Cache): not a "
+                            "fraction of the HBM roofline; `traffic_frac` is"}}
+    if world == 1 and not args.no_profile:
+        prof, note = profile_children(args, K, Wm)
+        roof["source"] = note
+        if prof:
+            n = K + Wm
+            v = prof["valu"][0]
+            valu = v.get("SQ_INSTS_VALU", 0.0) / n
+            roof["valu_instr_per_pass"] = valu
+            roof["achieved"] = round(valu / (ms_step * 1e-3) / 1e9, 2)
+            roof["frac"] = round(roof["achieved"] / VALU_PEAK_GINSTR, 4)
+            if v.get("SQ_ACTIVE_INST_VALU"):
+                roof["lane_util"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
+            pk = prof["valu"][1]
+            tot = sum(pk.values()) or 1.0
+            roof["kernel_share_of_valu"] = round(sum(x for k, x in pk.items() if k.startswith("k_trace")) / tot, 4)
+            roof["salu_instr_per_pass"] = v.get("SQ_INSTS_SALU", 0.0) / n
+            roof["vmem_read_instr_per_pass"] = v.get("SQ_INSTS_VMEM_RD", 0.0) / n
+            # HBM traffic: FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B; calibrated for wide streams — our 16-B gathers
+            # are uncalibrated, read it as an upper estimate), both counters in KB; counts Infinity-Cache hits too
+            fetch = prof["fetch"][0].get("FETCH_SIZE", 0.0) / n
+            write = prof["write"][0].get("WRITE_SIZE", 0.0) / n
+            traffic = (2.0 * fetch + write) * 1024.0
+            roof["traffic"] = traffic
+            roof["hbm"].update({"traffic_bytes_per_pass": traffic, "FETCH_SIZE_KB_per_pass": fetch, "WRITE_SIZE_KB_per_pass": write,
+                                "traffic_rate": round(traffic / (ms_step * 1e-3) / 1e9, 1),
+                                "traffic_frac": round(traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    else:
+        roof["source"] = "not collected (%s)" % ("--no-profile" if args.no_profile else "N > 1: one GPU's counters would not describe the job")
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample, rank 0, N=1 only ----
     cpu_baseline = None
@@ -207,55 +380,76 @@ def main():
         otree, _ = O.build_bvh(scene_descs)
         c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
         sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
-        P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], MAX_SEGMENTS, 0.01)
+        P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], segs, 0.01)
         acc = np.zeros((H, W, 4), np.float32)
         t1 = time.perf_counter()
         st = O.pt_pass(otree, c, W, H, P, O.randseeds(1)[0], 1, acc, nthreads=cores)
         dt = time.perf_counter() - t1
         cpu_baseline = {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                        "sample": "1 full pass of the same workload (%dx%d, depth %d, seed pass 0): " % (W, H, MAX_SEGMENTS) +
+                        "sample": "1 full pass of the same workload (%dx%d, depth %d, seed pass 0): " % (W, H, segs) +
                                   "%d rays in %.2f s; strict-fp32 CPU restatement, %d threads" % (st.rays, dt, cores),
                         "ms_per_frame": round(dt * 1e3, 1)}
+    glsl = LLVMPIPE_CONTAINER.get(args.workload) if (W, H) == (1920, 1080) else None
 
     out = {
-        "metric": "Mrays/s (closest-hit BVH queries: camera + bounce + Sun shadow rays), path tracing, 1 path/pixel/pass",
-        "value": round(mrays, 3),
+        "metric": "Mrays/s (closest-hit BVH queries as the reference performs them: camera + bounce + Sun shadow rays), path tracing, "
+                  "1 path/pixel/pass",
+        "value": round(rays / elapsed / 1e6, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
         "steps": K,
         "warmup": Wm,
-        "ms_per_step": round(elapsed / K * 1e3, 4),
+        "ms_per_step": round(ms_step, 4),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": (args.workload if (W, H) == (1920, 1080) else args.workload + " at another frame size") +
-                               (": Scene P (256 spheres + 16 discs), " if cfg2 else
-                                ": Scene D (dragon-class, 100352 triangles + floor disc), ") + "%dx%d, path tracing " % (W, H) +
-                               "depth %d (MAX_PATH_SEGMENTS=%d, MIN_WEIGHT=0.01), 1 path/pixel/pass, Sun direct lighting on, "
-                               % (MAX_SEGMENTS, MAX_SEGMENTS) + ("default camera" if cfg2 else "benchmark camera"),
+        "config": {"workload": (args.workload if (W, H) == (1920, 1080) else args.workload + " at another frame size") + ": " +
+                               WORKLOADS[args.workload]["text"] + ", %dx%d, path tracing depth %d (MAX_PATH_SEGMENTS=%d, MIN_WEIGHT=0.01), "
+                               % (W, H, segs, segs) + "1 path/pixel/pass, Sun direct lighting on, " + WORKLOADS[args.workload]["camera"],
                    "frame": [W, H], "parallelism": "8-row screen bands interleaved over %d rank(s)" % world,
+                   "gather": None if world == 1 else (gather_note or "gpuart_hip_gather (RCCL send/recv to rank 0 + row scatter), in the timed region"),
                    "bvh_nodes": info["nodes"], "bvh_primitives": info["prims"], "bvh_depth": info["max_depth"],
                    "scene_device_bytes": info["device_bytes"], "scene_setup_s": round(setup_s, 3)},
-        "ms_per_frame": round(elapsed / K * 1e3, 4),
+        "ms_per_frame": round(ms_step, 4),
+        "ms_per_frame_note": "throughput figure: wall time of the K passes / K, with up to 64 passes in flight between two observations",
+        "ms_per_frame_single": None if single_ms is None else round(single_ms, 4),
+        "ms_per_frame_single_note": "one pass submitted and observed alone (frame time of the reference's interactive loop), median of 5",
         "mpaths_per_s": round(W * H * K / elapsed / 1e6, 3),
         "rays_per_step": rays / K,
+        "rays_executed_per_step": exe[0] / K,
+        "mrays_executed_per_s": round(exe[0] / elapsed / 1e6, 3),
+        "nodes_per_step": nodes / K, "nodes_executed_per_step": exe[1] / K,
         "segments_per_step": segments / K,
-        "roofline": {"bound": "hbm", "achieved": round(achieved_per_launch, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_per_launch / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "k_trace (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
-                     "kernel_avg_ms": round(avg_kernel_ms, 5), "launches": launches, "concurrency": round(concurrency, 3),
-                     "achieved_aggregate": round(achieved_gbs, 2),
-                     "kernel_ms_per_pass": round(kernel_ms / K, 4),
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "algorithmic_bytes_per_pass": my_alg_bytes / K,
-                     "algorithmic_bytes_per_ray": round(alg_bytes / rays, 1) if rays else None},
+        "algorithmic_bytes_per_ray": round(alg_bytes / rays, 1) if rays else None,
+        "roofline": roof,
         "cpu_baseline": cpu_baseline,
+        "cpu_baseline_reference_glsl": None if glsl is None else {
+            "value": glsl["value"], "unit": "Mrays/s", "cores": 8, "kind": "reference", "ms_per_frame": glsl["ms_per_frame"],
+            "where": "BUILD CONTAINER (8 vCPU Xeon), not this box: the reference's unmodified GLSL on Mesa llvmpipe, same scene / camera / "
+                     "ray definition (tests/golden/time_llvmpipe.py; profiles/r02/llvmpipe_reference_glsl_container.txt)"},
     }
     print(json.dumps(out))
+    r.close()
+    shutil.rmtree(tmpdir, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+class _P2P:
+    """torch.distributed send/recv for host tensors over whatever backend is up (gloo: as is; nccl: staged through the device)."""
+
+    def __init__(self, dist, xdev):
+        self.dist, self.xdev = dist, xdev
+
+    def send(self, t, dst):
+        self.dist.send(t.to(self.xdev), dst=dst)
+
+    def recv(self, t, src):
+        buf = t.to(self.xdev)
+        self.dist.recv(buf, src=src)
+        t.copy_(buf)
 
 
 if __name__ == "__main__":

@@ -53,6 +53,7 @@ def hip_lib():
                                        "(make -C gpuart_amd/csrc); there is no CPU fallback" % HIP_LIB)
         L = C.CDLL(HIP_LIB, mode=C.RTLD_GLOBAL)
         L.gpuart_hip_last_error.restype = C.c_char_p
+        L.gpuart_hip_frame_row.restype = C.c_uint32
         _hip = L
     return _hip
 
@@ -67,7 +68,7 @@ def host_lib():
         L.gpuart_renderer_create.restype = C.c_void_p
         L.gpuart_renderer_backend.restype = C.c_void_p
         L.gpuart_renderer_path_tracing_pass.restype = C.c_uint
-        for name in ["destroy", "is_ok", "set_primitives", "init_box", "init_dragon", "set_camera", "update_viewport",
+        for name in ["destroy", "is_ok", "set_primitives", "init_box", "init_dragon", "init_cluster", "init_tree", "set_camera", "update_viewport",
                      "set_tile", "set_interleaved_tile", "set_sun", "set_user_sphere", "set_max_path_segments", "set_seed", "render_direct",
                      "restart_path_tracing", "path_tracing_pass", "read_direct", "read_radiance", "finish", "backend",
                      "save_checkpoint", "load_checkpoint",
@@ -143,6 +144,45 @@ def sun_direction(az, alt):
 
 
 # ---- device back end (include/gpuart_hip.h) -----------------------------------------------------------
+class TileGeom(C.Structure):
+    """gpuart_tile_geom (include/gpuart_hip.h): one rank's share of a frame sharded by rows."""
+    _fields_ = [("W", C.c_uint32), ("H", C.c_uint32), ("x0", C.c_uint32), ("y0", C.c_uint32), ("tw", C.c_uint32),
+                ("th", C.c_uint32), ("band_rows", C.c_uint32), ("band_stride", C.c_uint32)]
+
+    def rows(self):
+        """Frame rows of the share, in local row order."""
+        L = hip_lib()
+        return np.array([L.gpuart_hip_frame_row(C.byref(self), C.c_uint32(k)) for k in range(self.th)], np.int64)
+
+
+def share_of_rank(W, H, rank, nranks, band_rows=8):
+    """gpuart_hip_share_of_rank: bands of band_rows rows dealt round-robin to the ranks (pure host code)."""
+    g = TileGeom()
+    rc = hip_lib().gpuart_hip_share_of_rank(C.c_uint32(W), C.c_uint32(H), rank, nranks, C.c_uint32(band_rows), C.byref(g))
+    if rc:
+        raise ValueError("gpuart_hip_share_of_rank(%d, %d, %d, %d, %d) -> %d" % (W, H, rank, nranks, band_rows, rc))
+    return g
+
+
+def scatter_rows_host(g, tile_rgba, full_rgba):
+    """gpuart_hip_scatter_rows_host: rows of a share (th x tw x 4) into the full frame (H x W x 4), on the host."""
+    tile = np.ascontiguousarray(tile_rgba, np.float32)
+    assert tile.shape == (g.th, g.tw, 4) and full_rgba.shape == (g.H, g.W, 4) and full_rgba.flags["C_CONTIGUOUS"]
+    rc = hip_lib().gpuart_hip_scatter_rows_host(C.byref(g), _p(tile), _p(full_rgba))
+    if rc:
+        raise ValueError("gpuart_hip_scatter_rows_host -> %d" % rc)
+    return full_rgba
+
+
+def comm_unique_id():
+    """gpuart_hip_comm_unique_id (ncclGetUniqueId): 128 bytes for rank 0 to hand to the other ranks."""
+    buf = (C.c_ubyte * 128)()
+    L = hip_lib()
+    if L.gpuart_hip_comm_unique_id(buf):
+        raise HipError(L.gpuart_hip_last_error().decode())
+    return bytes(buf)
+
+
 class HipError(RuntimeError):
     pass
 
@@ -227,6 +267,26 @@ class Backend:
 
     def export(self, which, device_ptr, divide_by=1.0):
         self._chk(self.L.gpuart_hip_export(self.ctx, C.c_int(which), C.c_void_p(device_ptr), C.c_float(divide_by)))
+
+    def set_share(self, g):
+        self._chk(self.L.gpuart_hip_set_share(self.ctx, C.byref(g)))
+        self.tile = (g.x0, g.y0, g.tw, g.th)
+
+    def get_share(self):
+        g = TileGeom()
+        self._chk(self.L.gpuart_hip_get_share(self.ctx, C.byref(g)))
+        return g
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._chk(self.L.gpuart_hip_comm_init(self.ctx, nranks, rank, buf))
+
+    def comm_destroy(self):
+        self._chk(self.L.gpuart_hip_comm_destroy(self.ctx))
+
+    def gather(self, which, divide_by, root, full_frame_device_ptr):
+        """Collective: assembles every rank's share on `root` (full_frame_device_ptr: W*H*4 floats on the root, else 0)."""
+        self._chk(self.L.gpuart_hip_gather(self.ctx, which, C.c_float(divide_by), root, C.c_void_p(full_frame_device_ptr or None)))
 
     def finish(self):
         self._chk(self.L.gpuart_hip_finish(self.ctx))
@@ -342,6 +402,8 @@ class Renderer:
 
     def init_box(self): self.L.gpuart_renderer_init_box(self.h)
     def init_dragon(self, path): return bool(self.L.gpuart_renderer_init_dragon(self.h, path.encode()))
+    def init_cluster(self, path): return bool(self.L.gpuart_renderer_init_cluster(self.h, path.encode()))
+    def init_tree(self, path): return bool(self.L.gpuart_renderer_init_tree(self.h, path.encode()))
 
     def set_camera(self, cam):
         return bool(self.L.gpuart_renderer_set_camera(self.h, _f3(cam["pos"]), _f3(cam["dir"]), _f3(cam["up"]),

@@ -19,6 +19,7 @@
 #include "kernel_run.h"
 #include "kernels_test.h"
 #include "converter.h"
+#include "gather.h"
 
 // =================================================================================================
 // Host side: context, upload, launches
@@ -132,6 +133,13 @@ struct gpuart_hip_ctx {
     int timing_level = 1;  ///< 0 none, 1 per render call, 2 also per BVH-query kernel
     float *d_scratch = nullptr;  // test hooks
     size_t scratch_bytes = 0;
+    // multi-GPU gather (gather.h)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_nranks = 0;
+    bool comm_owned = false;          ///< made by gpuart_hip_comm_init / _init_all (destroyed with the context)
+    float4 *d_send = nullptr, *d_stage = nullptr;
+    size_t send_pixels = 0, stage_pixels = 0;
+    gpuart_tile_geom *d_geoms = nullptr;  ///< [1 + nranks]: own geometry, then everybody's (ncclAllGather)
 };
 
 namespace {
@@ -436,7 +444,9 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
         for (void *p : lp) if (p) (void)hipFree(p);
         if (l.main) (void)hipStreamDestroy(l.main);
     }
-    void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor};
+    if (c->comm && c->comm_owned && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
+    void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor,
+                    c->d_send, c->d_stage, c->d_geoms};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -855,6 +865,217 @@ int gpuart_hip_scene_info(gpuart_hip_ctx *c, uint64_t *nodes, uint64_t *prims, u
     if (prims) *prims = c->n_prims;
     if (max_depth) *max_depth = c->max_depth;
     if (device_bytes) *device_bytes = c->scene_bytes;
+    return 0;
+}
+
+// ---- shares and the multi-GPU gather (gather.h) ---------------------------------------------------------------------
+int gpuart_hip_set_share(gpuart_hip_ctx *c, const gpuart_tile_geom *g) {
+    if (!c || !g || !geom_ok(*g) || !g->th) return fail(GPUART_HIP_ERR_ARG, "bad share");
+    if (g->W != c->frame.W || g->H != c->frame.H) return fail(GPUART_HIP_ERR_ARG, "share of another frame size (call gpuart_hip_resize first)");
+    return gpuart_hip_set_tile_interleaved(c, g->x0, g->y0, g->tw, g->th, g->band_rows, g->band_stride);
+}
+
+int gpuart_hip_get_share(gpuart_hip_ctx *c, gpuart_tile_geom *g) {
+    if (!c || !g || !c->frame.W) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    g->W = c->frame.W; g->H = c->frame.H; g->x0 = c->frame.x0; g->y0 = c->frame.y0; g->tw = c->frame.tw; g->th = c->frame.th;
+    g->band_rows = c->frame.band_rows; g->band_stride = c->frame.band_stride;
+    return 0;
+}
+
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t e_ = (expr);                                                                       \
+        if (e_ != ncclSuccess)                                                                          \
+            return fail(GPUART_HIP_ERR_DEVICE, std::string(#expr) + ": " + rccl()->GetErrorString(e_)); \
+    } while (0)
+
+static int need_rccl() {
+    Rccl *r = rccl();
+    if (!r->err.empty()) return fail(GPUART_HIP_ERR_DEVICE, r->err);
+    return 0;
+}
+
+int gpuart_hip_comm_unique_id(void *id128) {
+    if (!id128) return fail(GPUART_HIP_ERR_ARG, "id == NULL");
+    int r = need_rccl();
+    if (r) return r;
+    static_assert(sizeof(ncclUniqueId) == GPUART_HIP_UNIQUE_ID_BYTES, "unique id size");
+    NCCL_TRY(rccl()->GetUniqueId((ncclUniqueId *)id128));
+    return 0;
+}
+
+static int comm_drop(gpuart_hip_ctx *c) {
+    if (c->comm && c->comm_owned) (void)rccl()->CommDestroy(c->comm);
+    c->comm = nullptr; c->comm_owned = false; c->comm_nranks = 0; c->comm_rank = 0;
+    return 0;
+}
+
+int gpuart_hip_comm_init(gpuart_hip_ctx *c, int nranks, int rank, const void *id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    int r = need_rccl();
+    if (r) return r;
+    HIP_TRY(hipSetDevice(c->device));
+    comm_drop(c);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCL_TRY(rccl()->CommInitRank(&c->comm, nranks, id, rank));
+    c->comm_owned = true; c->comm_nranks = nranks; c->comm_rank = rank;
+    return 0;
+}
+
+int gpuart_hip_comm_attach(gpuart_hip_ctx *c, void *nccl_comm, int nranks, int rank) {
+    if (!c || !nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    int r = need_rccl();
+    if (r) return r;
+    comm_drop(c);
+    c->comm = (ncclComm_t)nccl_comm; c->comm_owned = false; c->comm_nranks = nranks; c->comm_rank = rank;
+    return 0;
+}
+
+int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n) {
+    if (!ctxs || n < 1) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    int r = need_rccl();
+    if (r) return r;
+    std::vector<int> devs(n);
+    std::vector<ncclComm_t> comms(n);
+    for (int k = 0; k < n; k++) {
+        if (!ctxs[k]) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+        devs[k] = ctxs[k]->device;
+        for (int m = 0; m < k; m++)
+            if (devs[m] == devs[k]) return fail(GPUART_HIP_ERR_ARG, "two contexts of one communicator on the same device");
+    }
+    NCCL_TRY(rccl()->CommInitAll(comms.data(), n, devs.data()));
+    for (int k = 0; k < n; k++) {
+        comm_drop(ctxs[k]);
+        ctxs[k]->comm = comms[k]; ctxs[k]->comm_owned = true; ctxs[k]->comm_nranks = n; ctxs[k]->comm_rank = k;
+    }
+    return 0;
+}
+
+int gpuart_hip_comm_destroy(gpuart_hip_ctx *c) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    if (c->comm) { HIP_TRY(hipSetDevice(c->device)); int r = drain(c); if (r) return r; comm_drop(c); }
+    return 0;
+}
+
+namespace {
+int ensure_pixels(float4 *&buf, size_t &have, size_t want) {
+    if (have >= want && buf) return 0;
+    if (buf) { (void)hipFree(buf); buf = nullptr; have = 0; }
+    HIP_TRY(hipMalloc(&buf, std::max<size_t>(1, want) * sizeof(float4)));
+    have = want;
+    return 0;
+}
+
+/// One rank's part of a gather, to be called between ncclGroupStart and ncclGroupEnd: exports the (divided) tile and
+/// posts the send, or — on the root — the receives into the staging buffer. `all` = every rank's share.
+int gather_post(gpuart_hip_ctx *c, int which, float divide_by, int root, const std::vector<gpuart_tile_geom> &all) {
+    int r;
+    const int n = c->comm_nranks, me = c->comm_rank;
+    const size_t mine = (size_t)all[me].tw * all[me].th;
+    if (mine != c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "share table does not match this context's tile");
+    if (me != root) {
+        if ((r = ensure_pixels(c->d_send, c->send_pixels, mine))) return r;
+        if ((r = gpuart_hip_export(c, which, c->d_send, divide_by))) return r;
+        NCCL_TRY(rccl()->Send(c->d_send, mine * 4, ncclFloat, root, c->comm, c->stream));
+        return 0;
+    }
+    size_t total = 0;
+    for (int k = 0; k < n; k++) total += (size_t)all[k].tw * all[k].th;
+    if ((r = ensure_pixels(c->d_stage, c->stage_pixels, total))) return r;
+    size_t off = 0;
+    for (int k = 0; k < n; k++) {
+        const size_t cnt = (size_t)all[k].tw * all[k].th;
+        if (k == me) { if ((r = gpuart_hip_export(c, which, c->d_stage + off, divide_by))) return r; }
+        else if (cnt) NCCL_TRY(rccl()->Recv(c->d_stage + off, cnt * 4, ncclFloat, k, c->comm, c->stream));
+        off += cnt;
+    }
+    return 0;
+}
+
+/// After the group: the root scatters every share's rows into the full frame.
+int gather_place(gpuart_hip_ctx *c, const std::vector<gpuart_tile_geom> &all, float4 *full) {
+    size_t off = 0;
+    for (const gpuart_tile_geom &g : all) {
+        const size_t cnt = (size_t)g.tw * g.th;
+        if (cnt) k_scatter_rows<<<dim3((unsigned)((cnt + 255) / 256)), 256, 0, c->stream>>>(g, c->d_stage + off, full);
+        off += cnt;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_shares(const std::vector<gpuart_tile_geom> &all) {
+    uint64_t pixels = 0;
+    for (const gpuart_tile_geom &g : all) {
+        if (!geom_ok(g) || g.W != all[0].W || g.H != all[0].H) return fail(GPUART_HIP_ERR_ARG, "inconsistent shares");
+        pixels += (uint64_t)g.tw * g.th;
+    }
+    if (pixels > (uint64_t)all[0].W * all[0].H) return fail(GPUART_HIP_ERR_ARG, "shares overlap");
+    return 0;
+}
+}  // namespace
+
+int gpuart_hip_gather(gpuart_hip_ctx *c, int which, float divide_by, int root, void *full_frame_device) {
+    if (!c || !c->comm) return fail(GPUART_HIP_ERR_ARG, "no communicator (gpuart_hip_comm_init)");
+    if (root < 0 || root >= c->comm_nranks || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (c->comm_rank == root && !full_frame_device) return fail(GPUART_HIP_ERR_ARG, "the root needs a frame buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    const int n = c->comm_nranks;
+    // everybody's share, through the communicator itself (8 words per rank)
+    if (!c->d_geoms) HIP_TRY(hipMalloc(&c->d_geoms, (size_t)(1 + 1024) * sizeof(gpuart_tile_geom)));
+    if (n > 1024) return fail(GPUART_HIP_ERR_ARG, "more than 1024 ranks");
+    gpuart_tile_geom own;
+    if ((r = gpuart_hip_get_share(c, &own))) return r;
+    std::vector<gpuart_tile_geom> all(n);
+    HIP_TRY(hipMemcpyAsync(c->d_geoms, &own, sizeof own, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(rccl()->AllGather(c->d_geoms, c->d_geoms + 1, sizeof own / 4, ncclUint32, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(all.data(), c->d_geoms + 1, (size_t)n * sizeof own, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = check_shares(all))) return r;
+    NCCL_TRY(rccl()->GroupStart());
+    r = gather_post(c, which, divide_by, root, all);
+    ncclResult_t ge = rccl()->GroupEnd();
+    if (r) return r;
+    if (ge != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
+    if (c->comm_rank == root) return gather_place(c, all, (float4 *)full_frame_device);
+    return 0;
+}
+
+int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, void *full_frame_device) {
+    if (!ctxs || n < 1 || root < 0 || root >= n || !full_frame_device || (which != 0 && which != 1)) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    int r;
+    std::vector<gpuart_tile_geom> all(n);
+    for (int k = 0; k < n; k++) {
+        if (!ctxs[k] || !ctxs[k]->comm || ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k)
+            return fail(GPUART_HIP_ERR_ARG, "contexts are not the ranks 0..n-1 of one communicator (gpuart_hip_comm_init_all)");
+        if ((r = gpuart_hip_get_share(ctxs[k], &all[k]))) return r;
+    }
+    if ((r = check_shares(all))) return r;
+    NCCL_TRY(rccl()->GroupStart());
+    for (int k = 0; k < n && !r; k++) {
+        if (hipSetDevice(ctxs[k]->device) != hipSuccess) r = fail(GPUART_HIP_ERR_DEVICE, "hipSetDevice failed");
+        else r = gather_post(ctxs[k], which, divide_by, root, all);
+    }
+    ncclResult_t ge = rccl()->GroupEnd();
+    if (r) return r;
+    if (ge != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
+    HIP_TRY(hipSetDevice(ctxs[root]->device));
+    return gather_place(ctxs[root], all, (float4 *)full_frame_device);
+}
+
+int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, float *full_frame_host) {
+    if (!ctxs || n < 1 || root < 0 || root >= n || !ctxs[root] || !full_frame_host) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    gpuart_hip_ctx *c = ctxs[root];
+    const size_t bytes = (size_t)c->frame.W * c->frame.H * sizeof(float4);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = ensure_scratch(c, bytes);
+    if (r) return r;
+    if ((r = gpuart_hip_gather_all(ctxs, n, which, divide_by, root, c->d_scratch))) return r;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(full_frame_host, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

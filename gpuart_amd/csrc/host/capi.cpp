@@ -133,6 +133,12 @@ void gpuart_renderer_set_primitives(gpuart_renderer *r, const gpuart_prim_desc *
 }
 void gpuart_renderer_init_box(gpuart_renderer *r) { InitBox(r->impl); }
 int gpuart_renderer_init_dragon(gpuart_renderer *r, const char *plyPath) { return InitDragon(r->impl, plyPath) ? 1 : 0; }
+int gpuart_renderer_init_cluster(gpuart_renderer *r, const char *datPath) {
+    return (datPath ? InitCluster(r->impl, datPath) : InitCluster(r->impl)) ? 1 : 0;
+}
+int gpuart_renderer_init_tree(gpuart_renderer *r, const char *datPath) {
+    return (datPath ? InitTree(r->impl, datPath) : InitTree(r->impl)) ? 1 : 0;
+}
 int gpuart_renderer_set_camera(gpuart_renderer *r, const float pos[3], const float dir[3], const float up[3], float fovY,
                                float screenDist) {
     return r->impl.SetCamera(make_camera(pos, dir, up, fovY, screenDist)) ? 1 : 0;

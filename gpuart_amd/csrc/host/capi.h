@@ -43,6 +43,9 @@ int gpuart_renderer_is_ok(gpuart_renderer *r);
 void gpuart_renderer_set_primitives(gpuart_renderer *r, const gpuart_prim_desc *prims, int n, int printInfo);
 void gpuart_renderer_init_box(gpuart_renderer *r);
 int gpuart_renderer_init_dragon(gpuart_renderer *r, const char *plyPath);
+/* InitCluster / InitTree (reference src/scenes.cpp:69-103) on a primitive-list file; NULL = the reference's own path. */
+int gpuart_renderer_init_cluster(gpuart_renderer *r, const char *datPath);
+int gpuart_renderer_init_tree(gpuart_renderer *r, const char *datPath);
 int gpuart_renderer_set_camera(gpuart_renderer *r, const float pos[3], const float dir[3], const float up[3], float fovY,
                                float screenDist);
 int gpuart_renderer_update_viewport(gpuart_renderer *r, unsigned width, unsigned height);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -20,7 +21,8 @@ static void usage() {
     std::cerr << "usage: gpuart_cli [--scene box|ply:<file>|cluster|tree] [--width W] [--height H] [--mode direct|pt]\n"
                  "                  [--spp N] [--per-pass K] [--max-segments M] [--seed S] [--tile x0,y0,w,h]\n"
                  "                  [--camera px,py,pz] [--sun az,alt[,off]] [--user-sphere x,y,z,r,em[,specular[,fuzzy]]]\n"
-                 "                  [--device D] [--resume ck] [--checkpoint ck] [--pfm out.pfm] [--ppm out.ppm]\n";
+                 "                  [--device D] [--gpus N] [--resume ck] [--checkpoint ck] [--pfm out.pfm] [--ppm out.ppm]\n"
+                 "  --gpus N: path tracing of ONE frame on devices D..D+N-1 (8-row bands dealt round-robin, gathered over RCCL)\n";
 }
 
 static bool parse_floats(const char *s, float *out, int minN, int maxN, int &n) {
@@ -36,7 +38,7 @@ static bool parse_floats(const char *s, float *out, int minN, int maxN, int &n) 
 
 int main(int argc, char **argv) {
     std::string scene = "box", mode = "pt", pfm, ppm, resume, checkpoint;
-    unsigned W = 640, H = 480, spp = 16, perPass = 1, maxSeg = 5, device = 0;
+    unsigned W = 640, H = 480, spp = 16, perPass = 1, maxSeg = 5, device = 0, gpus = 1;
     long seed = -1;
     float tile[4] = {0, 0, 0, 0}, campos[3] = {0.1f, -3.05f, 1.0f}, sun[3] = {0, 0, 0}, us[7] = {-0.4f, 0, 0.2f, 0, 0, 0, 0};
     int nTile = 0, nSun = 0, nUs = 0, n;
@@ -55,6 +57,7 @@ int main(int argc, char **argv) {
         else if (a == "--max-segments") maxSeg = (unsigned)atoi(need("--max-segments"));
         else if (a == "--seed") seed = atol(need("--seed"));
         else if (a == "--device") device = (unsigned)atoi(need("--device"));
+        else if (a == "--gpus") gpus = (unsigned)atoi(need("--gpus"));
         else if (a == "--tile") { if (!parse_floats(need("--tile"), tile, 4, 4, nTile)) { usage(); return 2; } }
         else if (a == "--camera") { if (!parse_floats(need("--camera"), campos, 3, 3, n)) { usage(); return 2; } }
         else if (a == "--sun") { if (!parse_floats(need("--sun"), sun, 2, 3, nSun)) { usage(); return 2; } }
@@ -75,24 +78,34 @@ int main(int argc, char **argv) {
     cam.FovY = 60;
     cam.ScreenDist = 0.2f;
 
-    gpuart::Renderer r(W, H, cam, (int)device);
-    if (!r.GetIsOK()) { std::cerr << "Renderer initialization failed\n"; return 1; }
-    r.SetUserSphere(Vec3f(us[0], us[1], us[2]), us[3], us[4]);
-    if (nUs >= 6) r.SetUserSphereSpecular(us[5] != 0);
-    if (nUs >= 7) r.SetUserSphereFuzzy(us[6] != 0);
-    if (nSun >= 2) { r.SetSunAzimuth(sun[0]); r.SetSunAltitude(sun[1]); if (nSun == 3) r.SetSunDirectLighting(sun[2] == 0); }
-    r.SetMaxPathSegments(maxSeg);
-    if (seed >= 0) r.SetSeed((uint32_t)seed);
-
+    // One Renderer per GPU; with --gpus N every one is set up identically (same scene, camera, lighting, seed: all draw the
+    // same RandSeed sequence) and renders its share of the frame.
+    if (gpus < 1 || gpus > 64 || (gpus > 1 && (mode != "pt" || nTile == 4 || !resume.empty() || !checkpoint.empty()))) { usage(); return 2; }
+    std::vector<std::unique_ptr<gpuart::Renderer>> rs;
     bool ok = true;
-    if (scene == "box") InitBox(r);
-    else if (scene.compare(0, 4, "ply:") == 0) ok = InitDragon(r, scene.c_str() + 4);
-    else if (scene == "cluster") ok = InitCluster(r);
-    else if (scene == "tree") ok = InitTree(r);
-    else { usage(); return 2; }
-    if (!ok || !r.GetIsOK()) { std::cerr << "scene set-up failed\n"; return 1; }
+    for (unsigned g = 0; g < gpus && ok; g++) {
+        rs.emplace_back(new gpuart::Renderer(W, H, cam, (int)(device + g)));
+        gpuart::Renderer &r = *rs.back();
+        if (!r.GetIsOK()) { std::cerr << "Renderer initialization failed on device " << device + g << "\n"; return 1; }
+        r.SetUserSphere(Vec3f(us[0], us[1], us[2]), us[3], us[4]);
+        if (nUs >= 6) r.SetUserSphereSpecular(us[5] != 0);
+        if (nUs >= 7) r.SetUserSphereFuzzy(us[6] != 0);
+        if (nSun >= 2) { r.SetSunAzimuth(sun[0]); r.SetSunAltitude(sun[1]); if (nSun == 3) r.SetSunDirectLighting(sun[2] == 0); }
+        r.SetMaxPathSegments(maxSeg);
+        if (seed >= 0) r.SetSeed((uint32_t)seed);
+        if (scene == "box") InitBox(r);
+        else if (scene.compare(0, 4, "ply:") == 0) ok = InitDragon(r, scene.c_str() + 4);
+        else if (scene.compare(0, 8, "cluster:") == 0) ok = InitCluster(r, scene.c_str() + 8);
+        else if (scene.compare(0, 5, "tree:") == 0) ok = InitTree(r, scene.c_str() + 5);
+        else if (scene == "cluster") ok = InitCluster(r);
+        else if (scene == "tree") ok = InitTree(r);
+        else { usage(); return 2; }
+        if (!ok || !r.GetIsOK()) { std::cerr << "scene set-up failed\n"; return 1; }
+        if (gpus > 1 && !r.SetShare((int)g, (int)gpus)) return 1;
+    }
+    gpuart::Renderer &r = *rs[0];
     if (nTile == 4 && !r.SetTile((unsigned)tile[0], (unsigned)tile[1], (unsigned)tile[2], (unsigned)tile[3])) return 1;
-    const unsigned tw = r.GetTileWidth(), th = r.GetTileHeight();
+    const unsigned tw = gpus > 1 ? W : r.GetTileWidth(), th = gpus > 1 ? H : r.GetTileHeight();
 
     std::vector<float> img((size_t)tw * th * 4);
     const auto t0 = std::chrono::high_resolution_clock::now();
@@ -101,7 +114,7 @@ int main(int argc, char **argv) {
         r.RenderDirectLighting();
         ok = r.ReadDirectLighting(img.data());
     } else {
-        r.RestartPathTracing(perPass, spp);
+        for (auto &q : rs) q->RestartPathTracing(perPass, spp);
         if (!resume.empty()) {
             if (!r.LoadCheckpoint(resume.c_str())) return 1;
             // the checkpoint restores the run's own target (normally already reached); the command line's --spp /
@@ -109,11 +122,20 @@ int main(int argc, char **argv) {
             r.ExtendPathTracing(perPass, spp);
         }
         // the reference's draw loop: one pass per frame until pathsPerPixel is reached (src/main.cpp:554-582)
-        while ((done = r.RenderPathTracingPass()) < r.GetPathsPerPixel()) passes++;
-        passes++;
-        r.Finish();
+        // (every GPU's pass is only enqueued: the devices work at the same time)
+        for (;;) {
+            for (auto &q : rs) done = q->RenderPathTracingPass();
+            passes++;
+            if (done >= r.GetPathsPerPixel()) break;
+        }
+        for (auto &q : rs) q->Finish();
         if (!checkpoint.empty() && !r.SaveCheckpoint(checkpoint.c_str())) return 1;
-        ok = r.ReadRadiance(img.data(), true);
+        if (gpus > 1 || getenv("GPUART_CLI_FORCE_GATHER")) {  // (the variable: the RCCL path with a single rank, for tests)
+            std::vector<gpuart::Renderer *> ranks;
+            for (auto &q : rs) ranks.push_back(q.get());
+            ok = gpuart::Renderer::GatherRadiance(ranks.data(), (int)gpus, 0, true, img.data());
+        } else
+            ok = r.ReadRadiance(img.data(), true);
     }
     const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     if (!ok) return 1;
@@ -138,9 +160,9 @@ int main(int argc, char **argv) {
                 }
         fclose(f);
     }
-    printf("{\"scene\": \"%s\", \"mode\": \"%s\", \"frame\": [%u, %u], \"tile\": [%u, %u], \"paths_per_pixel\": %u, "
+    printf("{\"scene\": \"%s\", \"mode\": \"%s\", \"frame\": [%u, %u], \"tile\": [%u, %u], \"gpus\": %u, \"paths_per_pixel\": %u, "
            "\"passes\": %u, \"seconds\": %.6f, \"mpaths_per_s\": %.3f}\n",
-           scene.c_str(), mode.c_str(), W, H, tw, th, done, passes, secs,
+           scene.c_str(), mode.c_str(), W, H, tw, th, gpus, done, passes, secs,
            mode == "pt" ? (double)tw * th * done / secs / 1e6 : (double)tw * th / secs / 1e6);
     return 0;
 }

@@ -105,6 +105,34 @@ bool Renderer::SetInterleavedTile(unsigned x0, unsigned y0, unsigned w, unsigned
     return true;
 }
 
+bool Renderer::SetShare(int rank, int nranks) {
+    if (!Backend) return false;
+    gpuart_tile_geom g;
+    if (gpuart_hip_share_of_rank(Viewport.width, Viewport.height, rank, nranks, 8, &g) != 0 || g.th == 0) {
+        std::cerr << "Renderer: no share " << rank << " of " << nranks << " in a frame of " << Viewport.height << " rows." << std::endl;
+        return false;
+    }
+    return SetInterleavedTile(g.x0, g.y0, g.tw, g.th, g.band_rows, g.band_stride);
+}
+
+bool Renderer::GatherRadiance(Renderer *const *ranks, int n, int root, bool normalized, float *fullFrame) {
+    if (!ranks || n < 1 || root < 0 || root >= n || !fullFrame) return false;
+    std::vector<gpuart_hip_ctx *> ctxs((size_t)n);
+    for (int k = 0; k < n; k++) {
+        if (!ranks[k] || !ranks[k]->IsOK) return false;
+        ctxs[(size_t)k] = ranks[k]->Backend;
+    }
+    Renderer &r0 = *ranks[root];
+    // one communicator per set of renderers; made on first use, kept by the contexts
+    static std::vector<gpuart_hip_ctx *> joined;
+    if (joined != ctxs) {
+        if (!r0.Check(gpuart_hip_comm_init_all(ctxs.data(), n), "creating the RCCL communicator")) return false;
+        joined = ctxs;
+    }
+    const float div = normalized && r0.PathTracing.numPathsRendered ? (float)r0.PathTracing.numPathsRendered : 1.0f;
+    return r0.Check(gpuart_hip_gather_all_read(ctxs.data(), n, 1, div, root, fullFrame), "gathering the frame");
+}
+
 bool Renderer::SetCamera(const Camera &cam) {
     CurrentCamera = cam;
     if (!Backend) return false;

@@ -92,6 +92,15 @@ public:
     bool SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h);
     /// Row bands interleaved with other renderers (rank r of N: y0 = bandRows*r, bandStride = bandRows*N).
     bool SetInterleavedTile(unsigned x0, unsigned y0, unsigned w, unsigned localRows, unsigned bandRows, unsigned bandStride);
+    /// One frame on several GPUs: this renderer renders share `rank` of `nranks` — 8-row bands of
+    /// the frame dealt round-robin (gpuart_hip_share_of_rank). Every rank sets up the same scene, camera, lighting and
+    /// seed, so all ranks draw the same RandSeed sequence; nothing is exchanged per pass.
+    bool SetShare(int rank, int nranks);
+    /// Assembles the shares of `ranks[0..n)` (renderer k = SetShare(k, n), one GPU each, all driven by this thread) into
+    /// one frame in host memory: W*H RGBA32F, row 0 = bottom row. The rows travel over RCCL to `root`'s GPU
+    /// (gpuart_hip_gather_all), normalized = divided by the paths rendered. Replaces the normalise-to-display step of the
+    /// reference (src/renderer.cpp:601-616) for a frame that lives on several GPUs.
+    static bool GatherRadiance(Renderer *const *ranks, int n, int root, bool normalized, float *fullFrame);
     unsigned GetNumPathsRendered() const { return PathTracing.numPathsRendered; }
     /// Progressive-render checkpoint: accumulator + pass counters + RNG state of this tile.
     /// After LoadCheckpoint the following passes are bit-identical to those of the uninterrupted run. The

@@ -53,9 +53,9 @@ void InitBox(gpuart::Renderer &renderer) {
     submit(renderer, prims);
 }
 
-bool InitCluster(gpuart::Renderer &renderer) {
+bool InitCluster(gpuart::Renderer &renderer, const char *fileName) {
     std::vector<gpuart::Primitive *> prims;
-    if (!gpuart::Utils::LoadPrimitives(prims, "data/cluster_100k.dat", 0.01f, Vec3f(0, 0, 2.5f))) {
+    if (!gpuart::Utils::LoadPrimitives(prims, fileName, 0.01f, Vec3f(0, 0, 2.5f))) {
         discard(prims);
         return false;
     }
@@ -64,9 +64,9 @@ bool InitCluster(gpuart::Renderer &renderer) {
     return true;
 }
 
-bool InitTree(gpuart::Renderer &renderer) {
+bool InitTree(gpuart::Renderer &renderer, const char *fileName) {
     std::vector<gpuart::Primitive *> prims;
-    if (!gpuart::Utils::LoadPrimitives(prims, "data/tree1_21k.dat", 0.3f)) {
+    if (!gpuart::Utils::LoadPrimitives(prims, fileName, 0.3f)) {
         discard(prims);
         return false;
     }

@@ -50,36 +50,36 @@ def gather_bands(dist, band, bands, rank, full=None, root=0):
 def interleaved_rows(rank, world, height, band=8):
     """Frame rows owned by `rank` when row bands of `band` rows are dealt round-robin to the ranks
     (band k goes to rank k % world). Returns (y0, local_rows, band_rows, band_stride, rows) where `rows` is the
-    array of frame rows in local order — the arguments of gpuart_hip_set_tile_interleaved plus the scatter map."""
+    array of frame rows in local order. The layout itself is defined in C (gpuart_hip_share_of_rank, include/gpuart_hip.h);
+    this is its numpy restatement, kept for the tests that compare the two."""
     nbands = (height + band - 1) // band
     mine = np.arange(rank, nbands, world)
     rows = np.concatenate([np.arange(b * band, min(height, (b + 1) * band)) for b in mine]) if len(mine) else np.zeros(0, int)
     return rank * band, int(len(rows)), band, band * world, rows
 
 
-def gather_interleaved(dist, local, rank, world, height, full=None, root=0, band=8):
-    """Gathers interleaved row bands (local: (local_rows, W, C) tensor) into `full` (height, W, C) on root.
-    Point-to-point: the root posts all receives at once (every peer has its own xGMI link to the root), peers send."""
+def gather_shares_host(dist, tile, rank, world, W, H, full=None, root=0, band=8):
+    """Transport-agnostic form of gpuart_hip_gather for tensors in HOST memory (gloo): every rank sends the rows of its
+    share (tile: (th, W, 4) float32 tensor, share = gpuart_hip_share_of_rank), the root places them with the library's own
+    host scatter (gpuart_hip_scatter_rows_host). Used by the CPU tests (world size 2, 3 over gloo) and by bench.py only as
+    the announced fallback when the RCCL gather of the library cannot run. Returns `full` (H, W, 4) on root."""
     import torch
-    if rank == root:
-        bufs, ops = {}, []
-        for src in range(world):
-            _, n, _, _, rows = interleaved_rows(src, world, height, band)
-            if n == 0:
-                continue
-            if src == root:
-                bufs[src] = (local, rows)
-            else:
-                buf = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-                bufs[src] = (buf, rows)
-                ops.append(dist.P2POp(dist.irecv, buf, src))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for src, (buf, rows) in bufs.items():
-            full[torch.as_tensor(rows, device=full.device)] = buf
-        return full
-    if local.shape[0]:
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), root)]):
-            req.wait()
-    return None
+    from gpuart_amd import binding as B
+    shares = [B.share_of_rank(W, H, r, world, band) for r in range(world)]
+    assert tuple(tile.shape) == (shares[rank].th, W, 4), (tuple(tile.shape), shares[rank].th)
+    if rank != root:
+        if shares[rank].th:
+            dist.send(tile.contiguous(), dst=root)
+        return None
+    out = full.numpy() if isinstance(full, torch.Tensor) else full
+    for src in range(world):
+        g = shares[src]
+        if not g.th:
+            continue
+        if src == root:
+            part = tile
+        else:
+            part = torch.empty((g.th, W, 4), dtype=torch.float32)
+            dist.recv(part, src=src)
+        B.scatter_rows_host(g, part.numpy(), out)
+    return full

@@ -119,6 +119,49 @@ int gpuart_hip_write(gpuart_hip_ctx *ctx, int which, const float *rgba_host);
  * hands it to RCCL). Asynchronous on the context's stream; call gpuart_hip_finish before use. */
 int gpuart_hip_export(gpuart_hip_ctx *ctx, int which, void *rgba_device, float divide_by);
 
+/* ---- one frame on several GPUs ---------------------------------------------------------------
+ * The frame is sharded by rows: bands of `band_rows` rows dealt round-robin to the ranks; ranks exchange nothing per pass;
+ * when the passes are done every rank sends its rows to one root over RCCL (point-to-point over xGMI) and the root scatters
+ * them into the full frame on its device. Replaces the reference's normalise-to-display step for a frame that lives on
+ * several GPUs (reference src/renderer.cpp:601-616, shaders/pt_normalize.glsl:44-47: `divide_by`). */
+typedef struct gpuart_tile_geom {
+    uint32_t W, H;                    /* the frame */
+    uint32_t x0, y0, tw, th;          /* the share: tw x th local pixels; th may be 0 (more ranks than bands) */
+    uint32_t band_rows, band_stride;  /* local row ly = frame row y0 + (ly / band_rows) * band_stride + ly % band_rows */
+} gpuart_tile_geom;
+
+/* Pure host helpers (no device needed): rank's share of a W x H frame split over nranks in bands of band_rows rows (8 keeps
+ * the 8x8 pixel tiles of the path state intact); frame row of a local row; host version of the root's scatter. */
+int gpuart_hip_share_of_rank(uint32_t W, uint32_t H, int rank, int nranks, uint32_t band_rows, gpuart_tile_geom *out);
+uint32_t gpuart_hip_frame_row(const gpuart_tile_geom *g, uint32_t local_row);
+int gpuart_hip_scatter_rows_host(const gpuart_tile_geom *g, const float *tile_rgba, float *full_rgba);
+
+/* The context renders share `g` of its frame (= gpuart_hip_set_tile_interleaved); the share it currently renders. */
+int gpuart_hip_set_share(gpuart_hip_ctx *ctx, const gpuart_tile_geom *g);
+int gpuart_hip_get_share(gpuart_hip_ctx *ctx, gpuart_tile_geom *g);
+
+/* Communicator. One process per GPU: rank 0 obtains an id (gpuart_hip_comm_unique_id = ncclGetUniqueId), hands its
+ * GPUART_HIP_UNIQUE_ID_BYTES bytes to the other ranks by any means (bench.py: torch.distributed broadcast), every rank calls
+ * gpuart_hip_comm_init (= ncclCommInitRank on the context's device). One process driving several GPUs (gpuart_cli --gpus N):
+ * gpuart_hip_comm_init_all over its contexts (= ncclCommInitAll; context k becomes rank k). A caller that already owns an
+ * ncclComm_t attaches it instead (not destroyed with the context). RCCL is loaded on first use. */
+#define GPUART_HIP_UNIQUE_ID_BYTES 128
+int gpuart_hip_comm_unique_id(void *id128);
+int gpuart_hip_comm_init(gpuart_hip_ctx *ctx, int nranks, int rank, const void *id128);
+int gpuart_hip_comm_attach(gpuart_hip_ctx *ctx, void *nccl_comm, int nranks, int rank);
+int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n);
+int gpuart_hip_comm_destroy(gpuart_hip_ctx *ctx);
+
+/* Collective over the communicator: every rank contributes buffer `which` (0 direct lighting, 1 accumulator) of its share,
+ * divided by `divide_by`; on `root`, full_frame_device (W*H*4 floats in the root's device memory, frame row order) receives
+ * the assembled frame (other ranks pass NULL). Shares are exchanged through the communicator itself. Asynchronous on the
+ * contexts' streams after a short host synchronisation: call gpuart_hip_finish on the root before using the frame.
+ * gpuart_hip_gather_all is the same for the ranks 0..n-1 of a gpuart_hip_comm_init_all communicator, from one thread. */
+int gpuart_hip_gather(gpuart_hip_ctx *ctx, int which, float divide_by, int root, void *full_frame_device);
+int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, void *full_frame_device);
+/* gpuart_hip_gather_all into host memory (W*H*4 floats): the frame is assembled on the root's device, then read back. */
+int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, float *full_frame_host);
+
 /* glFlush() equivalent. gpuart_hip_pt_pass may only *collect* a pass: passes with identical parameters are launched
  * together as one run of the pipeline (slot = pass x pixel, up to 16M paths, so that the persistent BVH-query waves take
  * many rays per lane), and up to 8 runs are in flight at once on separate HIP streams (fewer when their path state would

@@ -827,3 +827,56 @@ def test_headless_cli_resume_continues_to_more_paths(tmp_path):
         assert out.returncode == 0, out.stderr
     assert '"paths_per_pixel": 8' in out.stdout
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_rccl_gather_with_one_rank(B, be, O):
+    """The gather of include/gpuart_hip.h on real RCCL, as far as one GPU allows: communicator of one rank (ncclGetUniqueId,
+    ncclCommInitRank through dlopen), share exchange (ncclAllGather), empty send/recv group, the root's export + row scatter
+    into a device frame — for a whole-frame share and for an interleaved share 1 of 3 (its rows land in their frame rows,
+    the rest of the frame stays untouched). The N > 1 transfers run on the driver's 8-GPU node; their host logic is covered
+    by tests/test_sharding_gloo.py."""
+    import torch
+    W, H = 72, 40
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    tree, _ = O.build_bvh(scene("box"))
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    be.comm_init(1, 0, B.comm_unique_id())
+    try:
+        for share in (B.share_of_rank(W, H, 0, 1), B.share_of_rank(W, H, 1, 3)):
+            be.set_share(share)
+            g = be.get_share()
+            assert (g.y0, g.th, g.band_stride) == (share.y0, share.th, share.band_stride)
+            be.pt_reset()
+            for seed in O.randseeds(2):
+                be.pt_pass(to_params(B, P), seed, 1)
+            tile = be.read(1, 2.0)
+            full = torch.full((H, W, 4), -7.0, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            be.gather(1, 2.0, 0, full.data_ptr())
+            be.finish()
+            got = full.cpu().numpy()
+            rows = g.rows()
+            assert_bits(got[rows].reshape(-1, 4), tile.reshape(-1, 4), "gathered rows")
+            rest = np.setdiff1d(np.arange(H), rows)
+            assert (got[rest] == -7.0).all()
+    finally:
+        be.comm_destroy()
+        be.set_tile(0, 0, W, H)
+
+
+def test_headless_cli_gather_path(tmp_path):
+    """gpuart_cli's multi-GPU read-out (Renderer::GatherRadiance -> gpuart_hip_gather_all over ncclCommInitAll) with the one
+    rank a single-GPU box allows == the plain read-back."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpuart_amd", "bin", "gpuart_cli")
+    base = [exe, "--scene", "box", "--width", "72", "--height", "40", "--mode", "pt", "--spp", "3"]
+    a, b = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+    out = subprocess.run(base + ["--pfm", a], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    env = dict(os.environ, GPUART_CLI_FORCE_GATHER="1")
+    out = subprocess.run(base + ["--pfm", b], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()

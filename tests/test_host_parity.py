@@ -153,3 +153,21 @@ def test_primitive_list_loader(tmp_path):
              (S.SPHERE, T([4, 4, 4]) + [float(f(mag) * f(1.0))])]
     b, _ = O.build_bvh(prims)
     assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("which", ["cluster", "tree"])
+def test_cluster_and_tree_stand_ins_load_like_the_reference_scenes(tmp_path, which):
+    """The synthetic stand-ins for data/cluster_100k.dat and data/tree1_21k.dat (gpuart_amd.synth_scenes), written in the
+    .dat dialect and loaded as InitCluster / InitTree load the originals (src/scenes.cpp:69-103: magnification 0.01 + lift
+    2.5, resp. magnification 0.3, then Disc((1,0,0),(0,0,1),6)): the C++ loader + BVH build give the tree the oracle builds
+    from the descriptions synth_scenes derives with the same float32 arithmetic (these are the trees behind
+    tests/golden/frames_cluster_*.npz / frames_tree_*.npz)."""
+    lines = S.cluster_dat_lines(6000, 7) if which == "cluster" else S.tree_dat_lines(6, 11)
+    load = S.CLUSTER_LOAD if which == "cluster" else S.TREE_LOAD
+    path = str(tmp_path / (which + ".dat"))
+    S.write_lines(path, lines)
+    a, _, n = B.compile_bvh_from_file("dat", path, load["magnification"], load["translation"], [S.FLOOR_DISC_CT])
+    descs = S.dat_descs(lines, **load) + [S.FLOOR_DISC_CT]
+    assert n == len(descs) - 1
+    b, _ = O.build_bvh(descs)
+    assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()

@@ -38,6 +38,23 @@ def test_interleaved_rows_partition_the_frame():
             assert (seen == 1).all()
 
 
+def test_c_share_layout_matches_the_numpy_restatement():
+    """gpuart_hip_share_of_rank / gpuart_hip_frame_row (pure host functions of libgpuart_hip.so) against interleaved_rows."""
+    from gpuart_amd import binding as B
+    for world in (1, 2, 3, 8):
+        for W, H in ((40, 8), (37, 61), (1920, 1080), (3840, 2160), (7680, 4320)):
+            seen = np.zeros(H, int)
+            for rank in range(world):
+                g = B.share_of_rank(W, H, rank, world)
+                y0, n, band, stride, rows = sharding.interleaved_rows(rank, world, H)
+                assert (g.W, g.H, g.x0, g.tw, g.y0, g.th, g.band_rows, g.band_stride) == (W, H, 0, W, y0, n, band, stride)
+                np.testing.assert_array_equal(g.rows(), rows)
+                seen[rows] += 1
+            assert (seen == 1).all()
+    with pytest.raises(ValueError):
+        B.share_of_rank(64, 64, 2, 2)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -61,14 +78,19 @@ def _worker(rank, world, port, H, W, q):
     dist.barrier()
     out = sharding.gather_bands(dist, band, bands, rank, full)
     dist.barrier()
-    # the interleaved form used by bench.py: 8-row bands dealt round-robin
-    _, n, _, _, rows = sharding.interleaved_rows(rank, world, H)
-    local = torch.from_numpy(_pixel_value(H, W)[rows].copy())
-    full2 = torch.zeros((H, W, 4)) if rank == 0 else None
-    out2 = sharding.gather_interleaved(dist, local, rank, world, H, full2)
-    dist.barrier()
+    # the interleaved shares bench.py and gpuart_cli --gpus use: the library's own layout + host scatter (the host half of gpuart_hip_gather), incl. a ragged last band
+    ok3 = True
+    for (h3, w3) in ((H, W), (61, 37), (8, 5)):
+        from gpuart_amd import binding as B
+        g = B.share_of_rank(w3, h3, rank, world)
+        mine = torch.from_numpy(_pixel_value(h3, w3)[g.rows()].copy()) if g.th else torch.zeros((0, w3, 4))
+        full3 = torch.full((h3, w3, 4), -1.0) if rank == 0 else None
+        out3 = sharding.gather_shares_host(dist, mine, rank, world, w3, h3, full3)
+        dist.barrier()
+        if rank == 0:
+            ok3 = ok3 and bool((out3.numpy() == _pixel_value(h3, w3)).all())
     if rank == 0:
-        ok = bool((out.numpy() == _pixel_value(H, W)).all()) and bool((out2.numpy() == _pixel_value(H, W)).all())
+        ok = bool((out.numpy() == _pixel_value(H, W)).all()) and ok3
         q.put((bands, ok))
     dist.destroy_process_group()
 
