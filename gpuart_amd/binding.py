@@ -130,6 +130,14 @@ def compile_bvh_from_file(kind, path, magnification=1.0, translation=(0, 0, 0), 
     return out, depth.value, nl.value
 
 
+def sort_permutation(keys, threads=8):
+    """gpuart_sort_permutation: the BVH build's parallel exact sort (csrc/host/exact_sort.h) on `keys`."""
+    k = np.ascontiguousarray(keys, np.float32)
+    perm = np.zeros(len(k), np.uint32)
+    host_lib().gpuart_sort_permutation(_p(k), C.c_size_t(len(k)), C.c_uint(threads), _p(perm))
+    return perm
+
+
 def camera_basis(pos, dir, up, fov_y, screen_dist, W, H):
     out = np.zeros(13, np.float32)
     host_lib().gpuart_camera_basis(_f3(pos), _f3(dir), _f3(up), C.c_float(fov_y), C.c_float(screen_dist), C.c_uint(W),

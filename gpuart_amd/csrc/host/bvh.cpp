@@ -5,6 +5,7 @@
 // with std::sort (float sum, compared as double), split at the first centre beyond the box
 // midpoint, never leaving a side empty when there are more than two primitives.
 #include "bvh.h"
+#include "exact_sort.h"
 
 #include <algorithm>
 #include <cassert>
@@ -13,6 +14,10 @@
 #include <cstring>
 #include <ostream>
 #include <system_error>
+#include <thread>
+#ifdef __linux__
+#include <sched.h>
+#endif
 
 namespace gpuart {
 
@@ -20,13 +25,16 @@ namespace {
 inline float as_float(uint32_t u) { float f; std::memcpy(&f, &u, sizeof f); return f; }
 inline uint32_t as_uint(float f) { uint32_t u; std::memcpy(&u, &f, sizeof u); return u; }
 
-template <int AXIS>
-struct CentreLess {
-    template <typename Item>
-    bool operator()(const Item &a, const Item &b) const {
-        return (a.lo[AXIS] + a.hi[AXIS]) * 0.5 < (b.lo[AXIS] + b.hi[AXIS]) * 0.5;
-    }
-};
+/// Threads a build may use: the cores this process may run on (not the machine's: a GPU box grants a share), at most 32.
+int build_threads() {
+    if (const char *e = std::getenv("GPUART_BVH_THREADS")) return std::max(1, std::atoi(e));
+    unsigned n = std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+#endif
+    return (int)std::min(32u, std::max(1u, n));
+}
 }  // namespace
 
 BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &primitives, unsigned maxNumLevels,
@@ -41,10 +49,9 @@ BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &pri
     }
     Subtree root;
     root.nodes.reserve(primitives.size() + 1);
-    // fork the top levels when the scene is large enough to pay for the threads (2^4 = 16 tasks at most)
-    int budget = primitives.size() >= 32768 ? 4 : 0;
-    if (const char *e = std::getenv("GPUART_BVH_FORK_LEVELS")) budget = std::atoi(e);
-    SubdivideParallel(root, items, 0, items.size(), 0, maxNumLevels, minPrimitivesPerNode, budget);
+    // threads are worth starting when the scene is large enough to pay for them
+    std::atomic<int> spare(primitives.size() >= 16384 ? build_threads() - 1 : 0);
+    SubdivideParallel(root, items, 0, items.size(), 0, maxNumLevels, minPrimitivesPerNode, spare);
     for (size_t i = 0; i < items.size(); i++) primitives[i] = items[i].p;  // the reference leaves the caller's list sorted too
     Nodes = std::move(root.nodes);
     LeafData = std::move(root.leafData);
@@ -53,7 +60,7 @@ BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &pri
 
 bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to,
                                            unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
-                                           size_t &split) {
+                                           size_t &split, std::atomic<int> &spareThreads, Scratch &scratch) {
     if (level > out.depth) out.depth = level;
     {
         Node &n = out.nodes[self];
@@ -83,10 +90,19 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
     else if (yr >= xr && yr >= zr) axis = 1;
     else axis = 2;
     const float range = axis == 0 ? xr : axis == 1 ? yr : zr;
-    auto first = prims.begin() + from, last = prims.begin() + to;
-    if (axis == 0) std::sort(first, last, CentreLess<0>());
-    else if (axis == 1) std::sort(first, last, CentreLess<1>());
-    else std::sort(first, last, CentreLess<2>());
+    // The reference sorts with std::sort on the box centres, 0.5 * (min + max) with the sum taken in float and the rest in
+    // double (src/bvh.cpp:96). Comparing the float sums gives the same answers, and sorting (key, position) pairs the same
+    // sequence of moves as sorting the primitives themselves; exact_sort.h performs that sort, large ones in parallel.
+    {
+        const size_t n = to - from;
+        if (scratch.keys.size() < n) { scratch.keys.resize(n); scratch.items.resize(n); }
+        SortKey *keys = scratch.keys.data();
+        for (size_t i = 0; i < n; i++) keys[i] = SortKey{prims[from + i].lo[axis] + prims[from + i].hi[axis], (uint32_t)i};
+        ExactSort::Sort(keys, keys + n, spareThreads);
+        Item *sorted = scratch.items.data();
+        for (size_t i = 0; i < n; i++) sorted[i] = prims[from + keys[i].index];
+        std::copy(sorted, sorted + n, prims.begin() + from);
+    }
 
     const double middle = out.nodes[self].lo[axis] + 0.5 * range;
     split = from;
@@ -100,23 +116,25 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
 
 void BoundingVolumesHierarchy::Subdivide(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
                                          unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent,
-                                         bool isLower) {
+                                         bool isLower, Scratch &scratch) {
     const uint32_t self = (uint32_t)out.nodes.size();
     out.nodes.emplace_back();
     out.nodes[self].parent = parent;
     out.nodes[self].isLower = isLower;
     size_t split;
-    if (PrepareNode(out, self, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split)) return;
-    Subdivide(out, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, self, true);
+    std::atomic<int> none(0);
+    if (PrepareNode(out, self, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split, none, scratch)) return;
+    Subdivide(out, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, self, true, scratch);
     out.nodes[self].higher = (uint32_t)out.nodes.size();
-    Subdivide(out, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, self, false);
+    Subdivide(out, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, self, false, scratch);
 }
 
 void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item> &prims, size_t from, size_t to,
                                                  unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
-                                                 int budget) {
-    if (budget <= 0 || to - from < 8192) {
-        Subdivide(out, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, 0, false);
+                                                 std::atomic<int> &spareThreads) {
+    Scratch scratch;  // of this task: a node's sort buffers are reused by the nodes below it
+    if (to - from < 8192) {
+        Subdivide(out, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, 0, false, scratch);
         return;
     }
     // this node (index 0 of `out`), then the two halves as independent subtrees spliced behind it in pre-order
@@ -124,20 +142,23 @@ void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item>
     out.nodes[0].parent = 0;
     out.nodes[0].isLower = false;
     size_t split;
-    if (PrepareNode(out, 0, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split)) return;
+    if (PrepareNode(out, 0, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split, spareThreads, scratch)) return;
+    { Scratch().swap(scratch); }  // the halves bring their own
     Subtree lo, hi;
-    // a lopsided split (one dominating primitive) is not worth a thread and does not use up the fork budget
-    const bool fork = std::min(split - from, to - split) >= 4096;
-    const int below = fork ? budget - 1 : budget;
-    auto buildLo = [&] { SubdivideParallel(lo, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, below); };
+    auto buildLo = [&] { SubdivideParallel(lo, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, spareThreads); };
     std::future<void> task;
-    if (fork) {
-        try {
-            task = std::async(std::launch::async, buildLo);
-        } catch (const std::system_error &) {  // no thread to be had: build this half here
-        }
+    // a lopsided split (one dominating primitive) is not worth a thread
+    if (std::min(split - from, to - split) >= 4096) {
+        if (spareThreads.fetch_sub(1) > 0) {
+            try {
+                task = std::async(std::launch::async, [&] { buildLo(); spareThreads.fetch_add(1); });
+            } catch (const std::system_error &) {  // no thread to be had: build this half here
+                spareThreads.fetch_add(1);
+            }
+        } else
+            spareThreads.fetch_add(1);
     }
-    SubdivideParallel(hi, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, below);
+    SubdivideParallel(hi, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, spareThreads);
     if (task.valid()) task.get();
     else buildLo();
     auto splice = [&out](Subtree &sub, bool isLower) {

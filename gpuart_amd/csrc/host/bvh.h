@@ -6,6 +6,7 @@
 #ifndef GPUART_BVH_H
 #define GPUART_BVH_H
 
+#include <atomic>
 #include <cstdint>
 #include <iosfwd>
 #include <vector>
@@ -13,6 +14,8 @@
 #include "core.h"
 
 namespace gpuart {
+
+struct SortKey;
 
 class BoundingVolumesHierarchy {
 public:
@@ -58,6 +61,12 @@ private:
         float lo[3], hi[3];
         Primitive *p;
     };
+    /// Sort buffers of one build task (exact_sort.h keys, the permuted primitives), grown on demand.
+    struct Scratch {
+        std::vector<SortKey> keys;
+        std::vector<Item> items;
+        void swap(Scratch &o) { keys.swap(o.keys); items.swap(o.items); }
+    };
     /// A subtree under construction: nodes in pre-order with indices relative to the subtree, its own leaf payloads.
     struct Subtree {
         std::vector<Node> nodes;
@@ -71,16 +80,18 @@ private:
 
     /// Sequential build of [from, to) appended to `out` (reference src/bvh.cpp:35-152).
     static void Subdivide(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
-                          unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent, bool isLower);
-    /// The same tree, built with the two halves of large nodes in parallel tasks; `budget` = how many
-    /// more levels may fork. Byte-identical to the sequential build: the per-node sort and split are unchanged, the
-    /// halves work on disjoint ranges of `prims`.
+                          unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent, bool isLower, Scratch &scratch);
+    /// The same tree, built in parallel: the two halves of large nodes by different threads, and the sort
+    /// of a large node itself by several (exact_sort.h: libstdc++'s introsort, re-scheduled). `spareThreads` = threads
+    /// that may still be started, shared by both. Byte-identical to the sequential build: every node's permutation is
+    /// the one std::sort produces, the halves work on disjoint ranges of `prims`.
     static void SubdivideParallel(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
-                                  unsigned maxNumLevels, unsigned minPrimitivesPerNode, int budget);
+                                  unsigned maxNumLevels, unsigned minPrimitivesPerNode, std::atomic<int> &spareThreads);
     /// Fills node `self` of `out` with the box of [from, to); returns true if it became a leaf, else sorts the range
     /// along the split axis and returns the split position.
     static bool PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
-                            unsigned maxNumLevels, unsigned minPrimitivesPerNode, size_t &split);
+                            unsigned maxNumLevels, unsigned minPrimitivesPerNode, size_t &split, std::atomic<int> &spareThreads,
+                            Scratch &scratch);
 };
 
 }  // namespace gpuart

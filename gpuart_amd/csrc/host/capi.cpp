@@ -1,5 +1,6 @@
 // capi.cpp — flat C API over the C++ library (see capi.h).
 #include "capi.h"
+#include "exact_sort.h"
 
 #include <cstdlib>
 #include <chrono>
@@ -103,6 +104,13 @@ int gpuart_compile_bvh_from_file(int kind, const char *path, float magnification
     if (ok && make_list(extra, extra ? nextra : 0, list)) rc = compile_list(list, 1024, 2, quads, nquads, depth);
     free_list(list);
     return rc;
+}
+
+void gpuart_sort_permutation(const float *keys, size_t n, unsigned threads, uint32_t *perm) {
+    std::vector<gpuart::SortKey> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = gpuart::SortKey{keys[i], (uint32_t)i};
+    gpuart::ExactSort::Sort(v.data(), v.data() + n, threads);
+    for (size_t i = 0; i < n; i++) perm[i] = v[i].index;
 }
 
 void gpuart_free(void *p) { free(p); }

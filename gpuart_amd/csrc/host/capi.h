@@ -30,6 +30,9 @@ int gpuart_compile_bvh_from_file(int kind, const char *path, float magnification
                                  const gpuart_prim_desc *extra, int nextra, float **quads, size_t *nquads,
                                  unsigned *depth, size_t *nloaded);
 void gpuart_free(void *p);
+/* The permutation the BVH build applies to a node's primitives: perm[i] = position (before sorting) of the element that
+ * std::sort leaves at i when sorting by `keys` with operator< — computed by exact_sort.h on up to `threads` threads. */
+void gpuart_sort_permutation(const float *keys, size_t n, unsigned threads, uint32_t *perm);
 /* out[13] = Pos(3) BottomLeft(3) DeltaHorz(3) DeltaVert(3) PixelSize */
 void gpuart_camera_basis(const float pos[3], const float dir[3], const float up[3], float fovY, float screenDist,
                          unsigned width, unsigned height, float out[13]);

@@ -132,6 +132,14 @@ def build_bvh(descs, max_levels=1024, min_prims=2):
     return out, md.value
 
 
+def sort_permutation(keys):
+    """std::sort with the reference's centre comparison (src/bvh.cpp:96) on `keys`: original positions in sorted order."""
+    k = np.ascontiguousarray(keys, np.float32)
+    perm = np.zeros(len(k), np.uint32)
+    lib().orc_sort_permutation(_p(k), C.c_size_t(len(k)), _p(perm))
+    return perm
+
+
 def camera(pos, dir, up, fov_y, screen_dist, W, H):
     """Returns 13 floats: pos(3) bottomLeft(3) deltaHorz(3) deltaVert(3) pixelSize."""
     out = np.zeros(13, np.float32)

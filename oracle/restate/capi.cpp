@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "device.h"
@@ -158,6 +159,16 @@ float *orc_build_bvh(const PrimDesc *prims, int n, unsigned maxLevels, unsigned 
     return o;
 }
 void orc_free(void *p) { free(p); }
+
+/// std::sort as the reference calls it (src/bvh.cpp:96): elements compared by centre = 0.5 * (float sum) in double.
+/// perm[i] = original position of the element left at i. (Checker for the product's parallel exact_sort.h.)
+void orc_sort_permutation(const float *keys, size_t n, uint32_t *perm) {
+    struct E { float k; uint32_t i; };
+    std::vector<E> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = E{keys[i], (uint32_t)i};
+    std::sort(v.begin(), v.end(), [](const E &a, const E &b) { return a.k * 0.5 < b.k * 0.5; });
+    for (size_t i = 0; i < n; i++) perm[i] = v[i].i;
+}
 
 /// out[16] = pos(3) bl(3) dh(3) dv(3) pixelSize
 void orc_camera(const float pos[3], const float dir[3], const float up[3], float fovY, float screenDist, unsigned W,

@@ -86,7 +86,7 @@ def test_parallel_bvh_build_is_byte_identical(fork_levels, monkeypatch):
     """the task-parallel build forks the halves of large nodes; whatever the number of forking levels
     (0 = the sequential algorithm of reference src/bvh.cpp:35-152), the compiled tree is the oracle's, byte for
     byte — 100 353 primitives incl. a disc that dominates the root box (a lopsided first split)."""
-    monkeypatch.setenv("GPUART_BVH_FORK_LEVELS", fork_levels)
+    monkeypatch.setenv("GPUART_BVH_THREADS", fork_levels)
     descs = S.scene_d()
     q, depth = B.compile_bvh(descs)
     ref, ref_depth = O.build_bvh(descs)
@@ -171,3 +171,39 @@ def test_cluster_and_tree_stand_ins_load_like_the_reference_scenes(tmp_path, whi
     assert n == len(descs) - 1
     b, _ = O.build_bvh(descs)
     assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def _sort_cases():
+    rng = np.random.RandomState(9)
+    n = 150000
+    yield "random", rng.uniform(-3, 3, n)
+    yield "heavy ties", rng.randint(0, 50, n).astype(np.float64)
+    yield "mesh-like ties", np.round(rng.uniform(-1, 1, n), 3)
+    yield "all equal", np.zeros(n)
+    yield "sorted", np.arange(n, dtype=np.float64)
+    yield "reversed", np.arange(n, dtype=np.float64)[::-1]
+    yield "organ pipe", np.concatenate([np.arange(n // 2), np.arange(n // 2)[::-1]]).astype(np.float64)
+    yield "sawtooth", (np.arange(n) % 17).astype(np.float64)
+    a = rng.uniform(-3, 3, n); a[rng.randint(0, n, 2000)] = np.nan; a[rng.randint(0, n, 500)] = np.inf; a[rng.randint(0, n, 500)] = -0.0
+    yield "NaN, inf, -0", a
+    # the classic median-of-three killer: drives introsort into its depth limit (heap sort of sub-ranges)
+    m = 60000
+    k = np.zeros(m)
+    half = m // 2
+    k[0::2][:half] = np.arange(1, half + 1)
+    k[1::2][:half] = np.arange(half + 1, 2 * half + 1) if m % 2 == 0 else 0
+    yield "median-of-3 killer", k
+    for size in (0, 1, 2, 3, 15, 16, 17, 31, 33, 100, 1000, 16385, 40000):
+        yield "size %d" % size, np.round(rng.uniform(0, 8, size), 1)
+
+
+def test_exact_sort_equals_std_sort():
+    """csrc/host/exact_sort.h (the BVH build's parallel sort) against std::sort with the reference's comparison
+    (src/bvh.cpp:96; oracle/restate/capi.cpp orc_sort_permutation): the same permutation — not just the same order of keys —
+    with ties, NaNs, adversarial patterns and the depth-limit (heap sort) path, on 1, 3 and 16 threads."""
+    for name, keys in _sort_cases():
+        k = keys.astype(np.float32)
+        want = O.sort_permutation(k)
+        for threads in (1, 3, 16):
+            got = B.sort_permutation(k, threads)
+            assert (got == want).all(), "%s, %d threads: %d positions differ" % (name, threads, int((got != want).sum()))

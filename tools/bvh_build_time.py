@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Times the host BVH build on Scene D: sequential (GPUART_BVH_FORK_LEVELS=0, the reference's
-algorithm as it stands) against the task-parallel build that is the default, in child processes so that the
-environment variable is read afresh; both must give the same bytes."""
-import hashlib
+"""Times the host BVH build: one thread (GPUART_BVH_THREADS=1, the reference's algorithm as it stands:
+std::sort per node) against the parallel build that is the default (halves of large nodes on different threads + the
+node's own sort on several, csrc/host/exact_sort.h), in child processes so that the environment variable is read afresh;
+all must give the same bytes.   python3 tools/bvh_build_time.py [scene_d|big|cluster]   (big = 871 200 triangles)"""
 import os
 import subprocess
 import sys
@@ -12,25 +12,29 @@ CHILD = r"""
 import sys, time, hashlib
 sys.path.insert(0, %r)
 from gpuart_amd import binding as B, synth_scenes as S
-p = B.make_prims(S.scene_d())
+which = sys.argv[1]
+descs = S.scene_d() if which == "scene_d" else S.scene_d(660, 660) if which == "big" else S.cluster_scene()
+p = B.make_prims(descs)
 best = 1e9
 for i in range(5):
     t = time.perf_counter(); q, depth = B.compile_bvh(p); best = min(best, time.perf_counter() - t)
-print("%%.1f %%s %%d" %% (best * 1e3, hashlib.sha256(q.tobytes()).hexdigest()[:16], depth))
+print("%%.1f %%s %%d %%d" %% (best * 1e3, hashlib.sha256(q.tobytes()).hexdigest()[:16], depth, len(descs)))
 """ % ROOT
 
 
 def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "scene_d"
     out = {}
-    for levels in ("0", "2", "4", "6"):
-        env = dict(os.environ, GPUART_BVH_FORK_LEVELS=levels)
-        r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, check=True)
-        ms, digest, depth = r.stdout.split()
-        out[levels] = (float(ms), digest)
-        print("fork levels %s: build+compile %.1f ms (best of 5), tree %s depth %s" % (levels, float(ms), digest, depth))
+    for threads in ("1", "2", "4", "8", "16", "default"):
+        env = dict(os.environ)
+        if threads != "default":
+            env["GPUART_BVH_THREADS"] = threads
+        r = subprocess.run([sys.executable, "-c", CHILD, which], env=env, capture_output=True, text=True, check=True)
+        ms, digest, depth, n = r.stdout.split()
+        out[threads] = (float(ms), digest)
+        print("%s (%s primitives), threads %-7s: build + compile %.1f ms (best of 5), tree %s depth %s" % (which, n, threads, float(ms), digest, depth))
     assert len({d for _, d in out.values()}) == 1, "trees differ"
-    print("cpus %d; speed-up of the default (4 levels) over sequential: %.2fx"
-          % (len(os.sched_getaffinity(0)), out["0"][0] / out["4"][0]))
+    print("cpus %d; speed-up of the default over one thread: %.2fx" % (len(os.sched_getaffinity(0)), out["1"][0] / out["default"][0]))
 
 
 if __name__ == "__main__":
