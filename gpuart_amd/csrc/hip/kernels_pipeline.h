@@ -370,8 +370,12 @@ __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_para
 // launches, which is what the interactive mode needs (one frame, then display).
 enum { DL_PRIMARY = 0, DL_SUN = 1, DL_EM = 2 };
 
+#ifndef GD_DIRECT_WAVES
+#define GD_DIRECT_WAVES 4  // waves per SIMD: the launch runs alone with 16 waves per CU, so 128 VGPRs are free to use (at 5
+                           // waves / 96 VGPRs the pixel's pending terms spilled to scratch)
+#endif
 template <int TYPES>
-__global__ void __launch_bounds__(BLOCK, GD_TRACE_WAVES) k_direct_persistent(Scene sc, Frame f, gpuart_params P, uint32_t n_slots,
+__global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Scene sc, Frame f, gpuart_params P, uint32_t n_slots,
                                                                           float4 *__restrict__ out, uint4 *spill, uint32_t *cursor,
                                                                           TraceTuning tune) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];

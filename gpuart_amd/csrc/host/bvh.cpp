@@ -54,8 +54,49 @@ BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &pri
     SubdivideParallel(root, items, 0, items.size(), 0, maxNumLevels, minPrimitivesPerNode, spare);
     for (size_t i = 0; i < items.size(); i++) primitives[i] = items[i].p;  // the reference leaves the caller's list sorted too
     Nodes = std::move(root.nodes);
-    LeafData = std::move(root.leafData);
     Depth = root.depth;
+    StoreLeaves(items, primitives.size() >= 16384 ? build_threads() : 1);
+}
+
+namespace {
+/// Runs body(k) for k in [0, parts) on `parts` threads (the caller's included).
+template <class F>
+void parallel_parts(int parts, F body) {
+    std::vector<std::future<void>> tasks;
+    for (int k = 1; k < parts; k++) {
+        try {
+            tasks.push_back(std::async(std::launch::async, body, k));
+        } catch (const std::system_error &) {
+            body(k);
+        }
+    }
+    body(0);
+    for (auto &t : tasks) t.get();
+}
+}  // namespace
+
+void BoundingVolumesHierarchy::StoreLeaves(const std::vector<Item> &prims, int threads) {
+    // payload length of every leaf: per primitive one type quad + 1..4 data quads (reference src/core.h:72-80)
+    size_t cursor = 0;
+    for (Node &n : Nodes) {
+        n.dataBegin = cursor;
+        for (uint32_t i = 0; i < n.count; i++) cursor += prims[n.primFirst + i].p->GetBVHDataLength();
+        n.dataEnd = cursor;
+    }
+    LeafData.assign(cursor, 0.0f);
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, Nodes.size() / 4096));
+    parallel_parts(parts, [&](int k) {
+        const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
+        Primitive::Data one;
+        for (size_t i = a; i < b; i++) {
+            const Node &n = Nodes[i];
+            if (!n.count) continue;
+            one.clear();
+            for (uint32_t j = 0; j < n.count; j++) prims[n.primFirst + j].p->StoreIntoBVH(one);
+            assert(one.size() == n.dataEnd - n.dataBegin);
+            std::copy(one.begin(), one.end(), LeafData.begin() + n.dataBegin);
+        }
+    });
 }
 
 bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to,
@@ -64,7 +105,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
     if (level > out.depth) out.depth = level;
     {
         Node &n = out.nodes[self];
-        n.higher = 0; n.count = 0; n.dataBegin = n.dataEnd = 0;
+        n.higher = 0; n.count = 0; n.primFirst = 0; n.dataBegin = n.dataEnd = 0;
         for (int k = 0; k < 3; k++) { n.lo[k] = 99.0e+29f; n.hi[k] = -99.0e+29f; }
         for (size_t i = from; i < to; i++)
             for (int k = 0; k < 3; k++) {
@@ -79,9 +120,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
     if (to - from <= minPrimitivesPerNode || level == maxNumLevels - 1) {
         Node &n = out.nodes[self];
         n.count = (uint32_t)(to - from);
-        n.dataBegin = out.leafData.size();
-        for (size_t i = from; i < to; i++) prims[i].p->StoreIntoBVH(out.leafData);
-        n.dataEnd = out.leafData.size();
+        n.primFirst = (uint32_t)from;
         return true;
     }
 
@@ -161,19 +200,18 @@ void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item>
     SubdivideParallel(hi, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, spareThreads);
     if (task.valid()) task.get();
     else buildLo();
+    out.nodes.reserve(1 + lo.nodes.size() + hi.nodes.size());
     auto splice = [&out](Subtree &sub, bool isLower) {
         const uint32_t base = (uint32_t)out.nodes.size();
-        const size_t dataBase = out.leafData.size();
-        for (size_t i = 0; i < sub.nodes.size(); i++) {
-            Node n = sub.nodes[i];
-            if (i == 0) { n.parent = 0; n.isLower = isLower; }
-            else n.parent += base;
-            if (n.higher) n.higher += base;
-            n.dataBegin += dataBase;
-            n.dataEnd += dataBase;
-            out.nodes.push_back(n);
+        out.nodes.insert(out.nodes.end(), sub.nodes.begin(), sub.nodes.end());
+        Node *n = out.nodes.data() + base;
+        n[0].parent = 0; n[0].isLower = isLower;
+        if (n[0].higher) n[0].higher += base;
+        for (size_t i = 1; i < sub.nodes.size(); i++) {
+            n[i].parent += base;
+            if (n[i].higher) n[i].higher += base;
         }
-        out.leafData.insert(out.leafData.end(), sub.leafData.begin(), sub.leafData.end());
+        std::vector<Node>().swap(sub.nodes);
         if (sub.depth > out.depth) out.depth = sub.depth;
     };
     splice(lo, true);
@@ -192,23 +230,27 @@ void BoundingVolumesHierarchy::Compile(Primitive::Data &out) const {
         cursor += 3 + (Nodes[i].dataEnd - Nodes[i].dataBegin) / RGBA_ELEMS;
     }
     assert(cursor * RGBA_ELEMS <= (size_t)1 << 31);
-    out.reserve(cursor * RGBA_ELEMS);
-    for (size_t i = 0; i < Nodes.size(); i++) {
-        const Node &n = Nodes[i];
-        uint32_t flags = (n.isLower ? IS_LOWER : 0) | (i == 0 ? IS_ROOT : 0);
-        const float parentBits = as_float(i == 0 ? 0u : addr[n.parent]);
-        const float quads[8] = {n.lo[0], n.lo[1], n.lo[2], RGBA_PAD, n.hi[0], n.hi[1], n.hi[2], RGBA_PAD};
-        out.insert(out.end(), quads, quads + 8);
-        if (n.count == 0 && n.higher != 0) {
-            const float info[4] = {as_float(flags), as_float(addr[i + 1]), as_float(addr[n.higher]), parentBits};
-            out.insert(out.end(), info, info + 4);
-        } else {
-            flags |= LEAF | (n.count & ~FLAGS_MASK);
-            const float info[4] = {as_float(flags), RGBA_PAD, RGBA_PAD, parentBits};
-            out.insert(out.end(), info, info + 4);
-            out.insert(out.end(), LeafData.begin() + n.dataBegin, LeafData.begin() + n.dataEnd);
+    out.resize(cursor * RGBA_ELEMS);
+    float *const dst = out.data();
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)(Nodes.size() >= 65536 ? build_threads() : 1), Nodes.size() / 4096));
+    parallel_parts(parts, [&](int k) {
+        const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
+        for (size_t i = a; i < b; i++) {
+            const Node &n = Nodes[i];
+            float *q = dst + (size_t)addr[i] * RGBA_ELEMS;
+            uint32_t flags = (n.isLower ? IS_LOWER : 0) | (i == 0 ? IS_ROOT : 0);
+            const float parentBits = as_float(i == 0 ? 0u : addr[n.parent]);
+            q[0] = n.lo[0]; q[1] = n.lo[1]; q[2] = n.lo[2]; q[3] = RGBA_PAD;
+            q[4] = n.hi[0]; q[5] = n.hi[1]; q[6] = n.hi[2]; q[7] = RGBA_PAD;
+            if (n.count == 0 && n.higher != 0) {
+                q[8] = as_float(flags); q[9] = as_float(addr[i + 1]); q[10] = as_float(addr[n.higher]); q[11] = parentBits;
+            } else {
+                flags |= LEAF | (n.count & ~FLAGS_MASK);
+                q[8] = as_float(flags); q[9] = RGBA_PAD; q[10] = RGBA_PAD; q[11] = parentBits;
+                std::copy(LeafData.begin() + n.dataBegin, LeafData.begin() + n.dataEnd, q + 12);
+            }
         }
-    }
+    });
 }
 
 void BoundingVolumesHierarchy::Print(const Primitive::Data &t, std::ostream &s) {

@@ -54,7 +54,8 @@ private:
         uint32_t higher;        ///< index of the upper child; 0 for leaves (the lower child is index+1)
         bool isLower;
         uint32_t count;         ///< primitives in a leaf (0 = interior node)
-        size_t dataBegin, dataEnd;  ///< leaf payload range in LeafData (floats)
+        uint32_t primFirst;     ///< leaf: position of its first primitive in the sorted primitive list
+        size_t dataBegin, dataEnd;  ///< leaf payload range in LeafData (floats); filled in once the tree is complete
     };
     /// A primitive during the build: its box and itself.
     struct Item {
@@ -67,12 +68,14 @@ private:
         std::vector<Item> items;
         void swap(Scratch &o) { keys.swap(o.keys); items.swap(o.items); }
     };
-    /// A subtree under construction: nodes in pre-order with indices relative to the subtree, its own leaf payloads.
+    /// A subtree under construction: nodes in pre-order with indices relative to the subtree (leaves refer to their
+    /// primitives by position in the list: a subtree only ever reorders its own range of it).
     struct Subtree {
         std::vector<Node> nodes;
-        std::vector<float> leafData;
         unsigned depth = 0;  ///< deepest level reached (absolute)
     };
+    /// Serialises the primitives of all leaves into LeafData (Primitive::StoreIntoBVH), several threads on node ranges.
+    void StoreLeaves(const std::vector<Item> &prims, int threads);
     std::vector<Node> Nodes;          ///< pre-order
     std::vector<float> LeafData;      ///< serialised primitives of all leaves, in leaf order
     size_t NumPrimitives = 0;

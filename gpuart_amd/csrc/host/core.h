@@ -27,6 +27,11 @@ public:
 
     /// Appends {type bits, pad, pad, pad} followed by the type's payload quads.
     void StoreIntoBVH(Data &data) const;
+    /// Number of floats StoreIntoBVH appends: the type quad + 1 (sphere), 2 (disc), 3 (triangle) or 4 (cone) data quads.
+    size_t GetBVHDataLength() const {
+        static const size_t DATA_QUADS[4] = {1, 2, 3, 4};
+        return 4 * (1 + DATA_QUADS[GetType() & 3]);
+    }
 
     float GetXmin() const { return Xmin; }
     float GetXmax() const { return Xmax; }

@@ -1,22 +1,33 @@
 # Collects the judged evidence of the current build on the GPU box:  bash tools/profile_round.sh <name>
-#   gpurun_out/<name>/{kernel_stats.csv, bench.json, pmc_traffic.json}; copy into profiles/<name>/ afterwards.
+#   gpurun_out/<name>/...; copy into profiles/<name>/ afterwards.
 set -e
 NAME=${1:-prof}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$NAME
-CMD="bench.py --steps 16 --warmup 8 --no-cpu-baseline"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the kernel trace profiles the DEFAULT bench command, so that its averages can be held against bench.json
-timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o x -- python3 $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
-timeout -k 10 250 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o x -- python3 $R/$CMD > $OUT/fetch.log 2>&1
-timeout -k 10 250 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write -o x -- python3 $R/$CMD > $OUT/write.log 2>&1
+# the kernel trace profiles the DEFAULT bench command (minus its own rocprofv3 child runs and the CPU baseline), so that its
+# averages can be held against the HIP-event figures of the same process
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o x -- python3 $R/bench.py --no-cpu-baseline --no-profile > $OUT/trace.log 2>&1
 cd $R
 cp $OUT/trace/x_kernel_stats.csv $OUT/kernel_stats.csv
 python3 tools/trace_agreement.py $OUT/trace/x_kernel_trace.csv $OUT/trace.log > $OUT/trace_vs_events.txt
-python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json "python3 $CMD" > /dev/null
-cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-timeout -k 10 250 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -1 $OUT/bench.json
-head -8 $OUT/kernel_stats.csv
-rm -rf $OUT/trace $OUT/fetch $OUT/write
+rm -rf $OUT/trace
+timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+for w in cfg2 cluster tree; do timeout -k 10 400 python3 bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
+timeout -k 10 400 python3 bench.py --frame 3840x2160 --steps 16 --warmup 4 > $OUT/bench_4k.json 2> $OUT/bench_4k.err
+timeout -k 10 400 python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile > $OUT/bench_steps1.json 2> $OUT/bench_steps1.err
+python3 tools/tile_overhead.py > $OUT/tile_scaling_one_gpu.txt 2>&1
+python3 tools/time_direct.py > $OUT/direct_lighting.txt 2>&1
+(python3 tools/bvh_build_time.py scene_d; python3 tools/bvh_build_time.py big; for s in scene_d big cluster tree; do python3 tools/setprims_time.py $s; done) > $OUT/bvh_build.txt 2>&1
+timeout -k 10 200 tools/ubench/ubench > $OUT/ubench.txt 2>&1
+python3 - <<PY
+import json
+for f in ["bench", "bench_cfg2", "bench_cluster", "bench_tree", "bench_4k", "bench_steps1"]:
+    d = json.loads(open("$OUT/%s.json" % f).read().strip().split("\n")[-1])
+    r = d["roofline"]
+    print("%-14s %8.1f Mrays/s (executed %8.1f)  %.4f ms/step  single %s  valu frac %s  lane_util %s  traffic_frac %s  cpu %s" % (
+        f, d["value"], d["mrays_executed_per_s"], d["ms_per_step"], d["ms_per_frame_single"], r.get("frac"), r.get("lane_util"),
+        r["hbm"].get("traffic_frac"), (d.get("cpu_baseline") or {}).get("value")))
+PY
+cat $OUT/trace_vs_events.txt $OUT/tile_scaling_one_gpu.txt $OUT/bvh_build.txt | tail -30

@@ -14,13 +14,13 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 line = [l for l in open(sys.argv[2]).read().split("\n") if l.startswith("{")][-1]
 d = json.loads(line)
-n = d["roofline"]["launches"]
+n = d["roofline"]["kernel_launches"]
 sel = rows[-n:]
 avg = sum(e - s for s, e in sel) / len(sel) / 1e6
-print("command: python3 bench.py --steps %d --warmup %d --no-cpu-baseline (under rocprofv3 --kernel-trace --stats)" % (d["steps"], d["warmup"]))
+print("command: python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-profile (under rocprofv3 --kernel-trace --stats)" % (d["steps"], d["warmup"]))
 print("k_trace launches in the timed region: %d" % n)
 print("rocprofv3 kernel trace, average duration of those launches: %.4f ms" % avg)
 print("bench.py HIP events (roofline.kernel_avg_ms):                %.4f ms" % d["roofline"]["kernel_avg_ms"])
 print("ratio: %.3f" % (avg / d["roofline"]["kernel_avg_ms"]))
-print("bench line of the profiled run: value %.1f %s, ms_per_step %.4f, roofline.achieved %.1f GB/s, frac %.3f"
-      % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["frac"]))
+print("bench line of the profiled run: value %.1f %s, ms_per_step %.4f, k_trace launch durations summed per pass %.3f ms, concurrency %.2f"
+      % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms_summed_per_pass"], d["roofline"]["kernel_concurrency"]))
