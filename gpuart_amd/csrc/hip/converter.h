@@ -22,6 +22,7 @@ struct Converter {
     size_t num_nodes = 0;
     uint32_t type_mask = 0;
     uint32_t max_depth = 0;
+    uint32_t top_depth = 0;  ///< records of nodes above this level are marked (pad word of the record; counters only)
     std::string err;
 
     static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -122,7 +123,7 @@ struct Converter {
         sanitize(L); sanitize(H);
         recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
         recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
-        recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], 0);
+        recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], fbits(depth < top_depth ? 1u : 0u));
         recs[4 * r + 3] = make_float4(H.bmax[0], H.bmax[1], H.bmax[2], 0);
         out.ref = (uint32_t)r;
         return true;

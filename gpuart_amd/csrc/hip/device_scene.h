@@ -36,6 +36,7 @@ struct Scene {
     uint32_t root_ref;    ///< record index, or GD_REF_LEAF | first primitive
 };
 
+
 struct Ray {
     F3 o, d;
 };
@@ -48,6 +49,7 @@ struct Surface {
 
 struct WorkCounters {
     uint32_t rays, nodes, prims[4];
+    uint32_t steps, steps_top;  ///< interior-node visits (record fetches); those of records the uploader marked "top of the tree"
 };
 
 // ---- reference shaders/sphere.glsl:31-70 -----------------------------------------------------
@@ -286,6 +288,12 @@ struct StackEntry {
     float pe, he;   ///< box-entry parameter of the parent / of the child itself (GD_ENTRY_MISS: box not hit)
 };
 
+#if (GD_RING & (GD_RING - 1)) == 0
+#define GD_RING_SLOT(i) ((i) & (GD_RING - 1))
+#else
+#define GD_RING_SLOT(i) ((i) % GD_RING)  // i < 1024 + GD_RING: a multiply-shift
+#endif
+
 struct TravStack {
     uint2 *ring_a;           ///< LDS, [GD_RING][BLOCK]: (ref, pe)
     float *ring_b;           ///< LDS, [GD_RING][BLOCK]: he
@@ -296,12 +304,12 @@ struct TravStack {
     GD_FN void reset() { sp = 0; base = 0; }
     GD_FN void push(StackEntry e) {
         if (sp - base == GD_RING) {
-            uint32_t o = (base & (GD_RING - 1)) * ring_stride;
+            uint32_t o = GD_RING_SLOT(base) * ring_stride;
             uint2 a = ring_a[o];
             spill[(size_t)base * spill_stride] = make_uint4(a.x, a.y, __float_as_uint(ring_b[o]), 0);
             base++;
         }
-        uint32_t o = (sp & (GD_RING - 1)) * ring_stride;
+        uint32_t o = GD_RING_SLOT(sp) * ring_stride;
         ring_a[o] = make_uint2(e.ref, __float_as_uint(e.pe));
         ring_b[o] = e.he;
         sp++;
@@ -310,12 +318,12 @@ struct TravStack {
         if (sp == base) {
             base--;
             uint4 v = spill[(size_t)base * spill_stride];
-            uint32_t o = (base & (GD_RING - 1)) * ring_stride;
+            uint32_t o = GD_RING_SLOT(base) * ring_stride;
             ring_a[o] = make_uint2(v.x, v.y);
             ring_b[o] = __uint_as_float(v.z);
         }
         sp--;
-        uint32_t o = (sp & (GD_RING - 1)) * ring_stride;
+        uint32_t o = GD_RING_SLOT(sp) * ring_stride;
         uint2 a = ring_a[o];
         StackEntry e;
         e.ref = a.x; e.pe = __uint_as_float(a.y); e.he = ring_b[o];
@@ -403,7 +411,11 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     // into scalar mask logic and ran 17 % slower — tools/ab.py)
     hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
     hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
-    if (COUNT) wc->nodes++;  // the lower child's box test (the upper one is counted when the reference reaches it)
+    if (COUNT) {
+        wc->nodes++;  // the lower child's box test (the upper one is counted when the reference reaches it)
+        wc->steps++;
+        wc->steps_top += __float_as_uint(q2.w) & 1u;  // the record's level is below GPUART_HIP_TOP_DEPTH (diagnostic)
+    }
     if (COUNT || hh) {
         StackEntry e;
         e.ref = __float_as_uint(q1.w); e.pe = t.entry; e.he = hh ? eh : GD_ENTRY_MISS;

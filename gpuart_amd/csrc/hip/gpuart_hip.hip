@@ -422,8 +422,8 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
             return fail(GPUART_HIP_ERR_DEVICE, "stream / event creation failed");
         }
     }
-    if (hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) {
+    if (hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return fail(GPUART_HIP_ERR_DEVICE, "counter allocation failed");
     }
     *out = c;
@@ -492,6 +492,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     HIP_TRY(hipSetDevice(c->device));
     Converter cv;
     cv.q = quads; cv.nq = nquads;
+    if (const char *e = getenv("GPUART_HIP_TOP_DEPTH")) cv.top_depth = (uint32_t)atoi(e);
     Converter::Child root;
     size_t tree_end = 0;
     if (!cv.node(0, 0, root, tree_end)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
@@ -833,7 +834,7 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
-    unsigned long long h[8];
+    unsigned long long h[16];
     int rr = drain(c);
     if (rr) return rr;
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -842,6 +843,8 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
         out->rays = h[0]; out->nodes = h[1];
         for (int k = 0; k < 4; k++) out->prim_tests[k] = h[2 + k];
         out->segments = h[6];
+        out->box_steps = h[7];
+        out->box_steps_top = h[8];
     }
     if (reset) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
     return 0;

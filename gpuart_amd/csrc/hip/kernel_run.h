@@ -49,7 +49,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     const unsigned long long below = (1ull << lane_id()) - 1;
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t segments = 0;
 
     // wave-uniform bookkeeping

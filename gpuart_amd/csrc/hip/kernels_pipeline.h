@@ -55,8 +55,8 @@ GD_FN int lane_id() { return threadIdx.x & 63; }
 
 GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned long long *g) {
     // one atomic per counter per wavefront
-    uint32_t v[7] = {wc.rays, wc.nodes, wc.prims[0], wc.prims[1], wc.prims[2], wc.prims[3], segments};
-    for (int k = 0; k < 7; k++) {
+    uint32_t v[9] = {wc.rays, wc.nodes, wc.prims[0], wc.prims[1], wc.prims[2], wc.prims[3], segments, wc.steps, wc.steps_top};
+    for (int k = 0; k < 9; k++) {
         unsigned long long s = v[k];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane_id() == 0 && s) atomicAdd(&g[k], s);
@@ -72,15 +72,20 @@ GD_FN bool slot_pixel(const Frame &f, uint32_t slot, uint32_t &lx, uint32_t &ly)
     return lx < f.tw && ly < f.th;
 }
 
-GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes) {
+/// The traversal stack of this lane: its column of the wave's LDS ring, its column of the launch's spill area
+/// (`wave` of `total_lanes / 64` waves).
+GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes, uint32_t wave) {
     TravStack st;
     st.ring_a = ring_a + lane_id();
     st.ring_b = ring_b + lane_id();
     st.ring_stride = BLOCK;
-    st.spill = spill + (size_t)blockIdx.x * BLOCK + lane_id();
+    st.spill = spill + (size_t)wave * BLOCK + lane_id();
     st.spill_stride = total_lanes;
     st.reset();
     return st;
+}
+GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes) {
+    return make_stack(ring_a, ring_b, spill, total_lanes, blockIdx.x);
 }
 
 /// Wave-aggregated append: lanes with `pred` get consecutive positions of `queue` (one atomic per wave).
@@ -173,18 +178,19 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         uint4 *spill, unsigned long long *gcounters, TraceTuning tune) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
-    TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
+    const uint32_t wave_id = blockIdx.x, n_waves = gridDim.x;  // one wavefront per workgroup
+    TravStack st = make_stack(ring_a, ring_b, spill, n_waves * BLOCK, wave_id);
     const uint32_t *queue_c = b.queue[seg_c & 1];
     const uint32_t n_c = seg_c >= 0 ? b.counters[4 * seg_c] : 0u;
     const uint32_t n = n_c + (seg_s >= 0 ? b.counters[4 * seg_s + 2] : 0u);
     uint32_t *cursor = &b.counters[seg_c >= 0 ? 4 * seg_c + 1 : 4 * seg_s + 3];
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
 
     // The first chunk of every wave is static (chunk index = workgroup index); later chunks come from the
     // shared cursor, which therefore starts behind the static ones. No atomic at all for small queues.
-    const uint32_t static_end = gridDim.x * tune.chunk;
-    uint32_t chunk_next = min(blockIdx.x * tune.chunk, n), chunk_end = min((blockIdx.x + 1) * tune.chunk, n);  // wave-uniform
+    const uint32_t static_end = n_waves * tune.chunk;
+    uint32_t chunk_next = min(wave_id * tune.chunk, n), chunk_end = min((wave_id + 1) * tune.chunk, n);  // wave-uniform
     bool exhausted = false;                                                                                   // wave-uniform
     uint32_t slot = SLOT_INVALID;
     bool shadow = false;                    // this lane's ray is a Sun-shadow query
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
       __syncthreads();
     }
     if (REFWORK) {
-        WorkCounters z = {0, 0, {0, 0, 0, 0}};
+        WorkCounters z = {0, 0, {0, 0, 0, 0}, 0, 0};
         flush_counters(z, segments, gcounters);
     }
 }
@@ -348,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_para
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;
         if (!slot_pixel(f, slot, lx, ly)) continue;
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
     F3 cw = f3(1, 1, 1), acc = f3(0, 0, 0), sun_term = f3(0, 0, 0), em_term = f3(0, 0, 0), em_dir = f3(0, 0, 0), ambient = f3(0, 0, 0);
     float em_dist = 0;
     Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
 
     auto start_query = [&](F3 o, F3 d) {
         ro = o; rd = d;
@@ -513,7 +519,7 @@ __global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_par
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t segments = 0;
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;

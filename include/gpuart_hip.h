@@ -58,6 +58,8 @@ typedef struct gpuart_counters {
     uint64_t nodes;         /* distinct BVH nodes whose box was tested, summed over rays */
     uint64_t prim_tests[4]; /* tested primitives by type: sphere, disc, triangle, cone */
     uint64_t segments;      /* path segments traced */
+    uint64_t box_steps;     /* interior-node visits (one 64-byte record fetch each) */
+    uint64_t box_steps_top; /* ... of nodes above level GPUART_HIP_TOP_DEPTH (environment, read at upload; diagnostic) */
 } gpuart_counters;
 
 const char *gpuart_hip_last_error(void);

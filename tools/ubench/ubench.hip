@@ -155,6 +155,43 @@ __global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ---- what a divergent per-lane record fetch costs by instruction width: 64 B as 4 x dwordx4, 56 B as 3 x dwordx4 + dwordx2,
+//      32 B as 2 x dwordx4, 64 B as 8 x dwordx2, 64 B as 16 x dword (every lane its own random 64-B record, dependent chain)
+template <int SHAPE>
+__global__ void __launch_bounds__(64) k_width(const float *__restrict__ recs, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
+    uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        const float *r = recs + 16 * (size_t)(idx & mask);
+        float s = 0; uint32_t h = 0;
+        if (SHAPE == 0) {
+            float4 a = ((const float4 *)r)[0], b = ((const float4 *)r)[1], c = ((const float4 *)r)[2], d = ((const float4 *)r)[3];
+            asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w), "+v"(d.w));
+            s = (a.x + b.y) + (c.z + d.x); h = __float_as_uint(a.w) + __float_as_uint(b.w) + __float_as_uint(c.w) + __float_as_uint(d.w);
+        } else if (SHAPE == 1) {
+            float4 a = ((const float4 *)r)[0], b = ((const float4 *)r)[1], c = ((const float4 *)r)[2]; float2 d = ((const float2 *)r)[6];
+            asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w), "+v"(d.y));
+            s = (a.x + b.y) + (c.z + d.x); h = __float_as_uint(a.w) + __float_as_uint(b.w) + __float_as_uint(c.w) + __float_as_uint(d.y);
+        } else if (SHAPE == 2) {
+            float4 a = ((const float4 *)r)[0], b = ((const float4 *)r)[1];
+            asm volatile("" : "+v"(a.w), "+v"(b.w));
+            s = a.x + b.y; h = __float_as_uint(a.w) + __float_as_uint(b.w);
+        } else if (SHAPE == 3) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { float2 a = ((const float2 *)r)[k]; asm volatile("" : "+v"(a.y)); s += a.x; h += __float_as_uint(a.y); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { float a = r[k]; asm volatile("" : "+v"(a)); s += a; h += __float_as_uint(a); }
+        }
+        acc += s;
+        idx = idx * 1664525u + 1013904223u + h;
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 struct Result { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Result> g_results;
 
@@ -260,6 +297,14 @@ int main(int argc, char **argv) {
             timed("load4x16B_contiguous", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<2><<<n, 64>>>(recs, m, 1024, o, c); }, "1 KB contiguous per instruction");
             timed("load4x16B_broadcast", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<3><<<n, 64>>>(recs, m, 1024, o, c); }, "all lanes one record");
             timed("load4x16B_16_lanes", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<4><<<n, 64>>>(recs, m, 1024, o, c); }, "16 active lanes, own records");
+        }
+        for (int w : {6}) {
+            const float *rf = (const float *)recs;
+            timed("fetch64B_4x_dwordx4", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<0><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed("fetch56B_3x_dwordx4_1x_dwordx2", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<1><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed("fetch32B_2x_dwordx4", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<2><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed("fetch64B_8x_dwordx2", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<3><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed("fetch64B_16x_dword", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<4><<<n, 64>>>(rf, m, 1024, o, c); });
         }
         CHECK(hipFree(recs));
     }
