@@ -18,10 +18,12 @@ What is counted:
     replay. The timed (fast) mode renders bit-identical images with less work — it skips Sun-shadow queries that cannot
     matter and stops them at the first hit — so `rays_executed` (counted in a second untimed replay, mode 4) is reported
     beside it, with its own rate.
-  * `roofline` is a device-level fraction: wave64 VALU instructions of all kernels of a pass (SQ_INSTS_VALU, collected by a
-    rocprofv3 child run of THIS invocation on the same passes) / ms_per_step, against the VALU issue peak. The HBM view
-    (algorithmic bytes, and the HBM traffic of the same child runs) is carried as secondary fields: the 8.7 MB tree is
-    cache-resident, so algorithmic bytes / time exceeds the HBM peak and is not a fraction of anything.
+  * `roofline` is a device-level fraction of the resource that binds the BVH queries, the vector L1: its cache accesses of
+    all kernels of a pass (TCP_TOTAL_CACHE_ACCESSES_sum, collected by a rocprofv3 child run of THIS invocation on the same
+    passes) / ms_per_step, against one access per cycle and CU (calibrated with tools/ubench; DESIGN.md section 4 for the
+    experiment that names this resource). The VALU-issue view (SQ_INSTS_VALU against 2 cycles per wave64 instruction) and
+    the HBM view (algorithmic bytes; HBM traffic of the same child runs) are carried as secondary fields: the 8.7 MB tree
+    is cache-resident, so algorithmic bytes / time exceeds the HBM peak and is not a fraction of anything.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -46,6 +48,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+L1_PEAK_GACC = 614.4            # 256 CUs x 2.4 GHz x ONE vector-L1 (TCP) cache access per cycle: TCP_TOTAL_CACHE_ACCESSES_sum saturates at
+                                # 5.9-6.7e11/s in every divergent or contiguous load pattern of tools/ubench (profiles/r02/l1_access_calibration.txt)
 VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling";
                                 # measured on the box: profiles/r02/ubench.txt)
 
@@ -137,6 +141,7 @@ def profile_children(args, K, Wm):
     out = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for tag, counters in (("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES"]),
+                          ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]),
                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
         d = tempfile.mkdtemp(prefix="gpuart_pmc_", dir="/tmp")
         try:
@@ -329,10 +334,15 @@ def main():
     # ---- roofline: device-level VALU issue fraction (+ HBM views), counters from rocprofv3 child runs of this invocation ----
     ms_step = elapsed / K * 1e3
     avg_kernel_ms = kernel_ms / max(1, launches)
-    roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s", "frac": None,
+    roof = {"bound": "l1_accesses", "achieved": None, "peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "frac": None,
             "traffic": None,
-            "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step (device level: overlapping launches are not double "
-                          "counted), against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+            "definition": "TCP_TOTAL_CACHE_ACCESSES_sum of every kernel of a pass / ms_per_step (device level: overlapping launches are not "
+                          "double counted), against 256 CUs x 2.4 GHz x one L1 access per cycle (tools/ubench saturates there in every "
+                          "load pattern). The BVH queries are bound by vector-memory requests: every extra 16-byte fetch per node visit costs "
+                          "+12 % whether it hits L1 or not (profiles/r02/vector_memory_bound.txt)",
+            "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s",
+                           "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step against 1024 SIMDs x 2.4 GHz / 2 cycles per "
+                                         "wave64 VALU instruction"},
             "kernel": "k_trace (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
             "kernel_avg_ms": round(avg_kernel_ms, 5), "kernel_launches": launches, "kernel_ms_summed_per_pass": round(kernel_ms / K, 4),
             "kernel_concurrency": round(kernel_ms / (elapsed * 1e3), 3),
@@ -350,16 +360,24 @@ def main():
             n = K + Wm
             v = prof["valu"][0]
             valu = v.get("SQ_INSTS_VALU", 0.0) / n
-            roof["valu_instr_per_pass"] = valu
-            roof["achieved"] = round(valu / (ms_step * 1e-3) / 1e9, 2)
-            roof["frac"] = round(roof["achieved"] / VALU_PEAK_GINSTR, 4)
+            vi = roof["valu_issue"]
+            vi["instr_per_pass"] = valu
+            vi["achieved"] = round(valu / (ms_step * 1e-3) / 1e9, 2)
+            vi["frac"] = round(vi["achieved"] / VALU_PEAK_GINSTR, 4)
             if v.get("SQ_ACTIVE_INST_VALU"):
-                roof["lane_util"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
+                vi["lane_util"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
             pk = prof["valu"][1]
             tot = sum(pk.values()) or 1.0
-            roof["kernel_share_of_valu"] = round(sum(x for k, x in pk.items() if k.startswith("k_trace")) / tot, 4)
-            roof["salu_instr_per_pass"] = v.get("SQ_INSTS_SALU", 0.0) / n
-            roof["vmem_read_instr_per_pass"] = v.get("SQ_INSTS_VMEM_RD", 0.0) / n
+            vi["kernel_share"] = round(sum(x for k, x in pk.items() if k.startswith("k_trace")) / tot, 4)
+            vi["salu_instr_per_pass"] = v.get("SQ_INSTS_SALU", 0.0) / n
+            vi["vmem_read_instr_per_pass"] = v.get("SQ_INSTS_VMEM_RD", 0.0) / n
+            tc = prof["tcp"][0]
+            acc = tc.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / n
+            roof["l1_cache_accesses_per_pass"] = acc
+            roof["l1_requests_before_coalescing_per_pass"] = tc.get("TCP_TOTAL_ACCESSES_sum", 0.0) / n
+            roof["l1_misses_to_l2_per_pass"] = tc.get("TCP_TCC_READ_REQ_sum", 0.0) / n
+            roof["achieved"] = round(acc / (ms_step * 1e-3) / 1e9, 2)
+            roof["frac"] = round(roof["achieved"] / L1_PEAK_GACC, 4)
             # HBM traffic: FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B; calibrated for wide streams — our 16-B gathers
             # are uncalibrated, read it as an upper estimate), both counters in KB; counts Infinity-Cache hits too
             fetch = prof["fetch"][0].get("FETCH_SIZE", 0.0) / n

@@ -85,7 +85,7 @@ struct Converter {
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
             uint32_t first = (uint32_t)(prims.size() / 3);
-            if (first >= 0x3ffffff0u) { err = "too many primitives"; return false; }
+            if (first >= 0x1ffffff0u) { err = "too many primitives"; return false; }
             size_t a = addr + 3;
             static const int LEN[4] = {1, 2, 3, 4};
             bool all_tris = n >= 1 && n <= 2;
@@ -105,7 +105,7 @@ struct Converter {
             if (n == 0) {  // empty leaf (empty scene): one dummy record with count 0
                 prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
             }
-            out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS : 0u) | first;
+            out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS | (n == 2 ? GD_REF_TWO : 0u) : 0u) | first;
             end = a;
             return true;
         }
@@ -113,7 +113,7 @@ struct Converter {
         if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
         if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
         const size_t r = recs.size() / 4;
-        if (r >= 0x3ffffff0u) { err = "too many nodes"; return false; }
+        if (r >= 0x1ffffff0u) { err = "too many nodes"; return false; }
         recs.resize(recs.size() + 4);
         Child L, H;
         size_t lo_end = 0;

@@ -6,7 +6,7 @@
 //           fetch of one 64-byte line serves two box tests:
 //             [4r]   = { lo.bbmin.xyz, bits(lo ref) }     ref = record index of an interior child, or
 //             [4r+1] = { lo.bbmax.xyz, bits(hi ref) }           bit31 | first primitive index of a leaf child
-//                                                               (| bit30 when the leaf is one or two triangles)
+//                                                               (| bit30 when the leaf is one or two triangles, | bit29 when two)
 //             [4r+2] = { hi.bbmin.xyz, 0 }
 //             [4r+3] = { hi.bbmax.xyz, 0 }
 //           The root's own box and ref travel in the Scene struct.
@@ -27,7 +27,8 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 
 #define GD_REF_LEAF 0x80000000u
 #define GD_REF_TRIS 0x40000000u  ///< with GD_REF_LEAF: the leaf holds only triangles, one or two of them
-#define GD_REF_INDEX 0x3fffffffu
+#define GD_REF_TWO 0x20000000u   ///< with GD_REF_TRIS: two of them (both records are fetched at once; a single-triangle leaf fetches one)
+#define GD_REF_INDEX 0x1fffffffu
 
 struct Scene {
     const float4 *__restrict__ recs;
@@ -248,18 +249,20 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &close
 }
 
 /// Leaf that holds one or two triangles (the common case of triangle meshes: the reference builds leaves of at
-/// most two primitives): both records are fetched and tested together. With a single triangle the second slot
-/// re-reads the first record; a repeated equal parameter can never replace the hit (`pos < closest` is strict).
+/// most two primitives). Which of the two it is travels in the leaf's ref, so both records of a pair are requested at
+/// once and a single-triangle leaf requests only its own (every 16-byte request counts: the BVH queries are bound by the
+/// vector-memory request pipeline). The first one wins ties (`pos < closest` is strict), as in the reference's loop.
 template <bool ANY_HIT, bool COUNT>
-GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool two, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
     const float4 *pa = sc.prims + 3 * (size_t)first;
-    float4 a0 = pa[0];
-    const uint32_t count = __float_as_uint(a0.w) >> 2;
-    const float4 *pb = count > 1 ? pa + 3 : pa;
-    float4 a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-    if (COUNT) wc->prims[P_TRIANGLE] += count;
+    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+    if (COUNT) wc->prims[P_TRIANGLE] += two ? 2 : 1;
+    float tb = -1.0f;
+    if (two) {
+        const float4 b0 = pa[3], b1 = pa[4], b2 = pa[5];
+        tb = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, b0, b1, b2);
+    }
     const float ta = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, a0, a1, a2);
-    const float tb = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, b0, b1, b2);
     if (ta > 0 && ta < closest) {
         closest = ta;
         hit_prim = first;
@@ -267,7 +270,7 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, float &
     }
     if (tb > 0 && tb < closest) {
         closest = tb;
-        hit_prim = first + 1;  // only reachable with count == 2
+        hit_prim = first + 1;
         if (ANY_HIT) return true;
     }
     return false;
@@ -338,7 +341,7 @@ struct TravStack {
 /// hit (same value: the test is a pure function of node and ray). The upper child's box is tested when
 /// its parent's record is fetched (both boxes share one 64-byte record) and the result waits on the
 /// stack; whether it is *used* is decided exactly where the reference decides it, at pop time.
-enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2, TRAV_LEAF_TRIS = 3 };
+enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2, TRAV_LEAF_TRIS = 3, TRAV_LEAF_TRI1 = 5 };  // odd: waiting at a leaf
 
 #define GD_ENTRY_MISS 3.0e+38f  // stack marker: the upper child's box is not hit at all
 
@@ -354,7 +357,7 @@ struct Trav {
 GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
     if (ref & GD_REF_LEAF) {
         t.node = ref & GD_REF_INDEX;
-        t.state = (ref & GD_REF_TRIS) ? TRAV_LEAF_TRIS : TRAV_LEAF;
+        t.state = !(ref & GD_REF_TRIS) ? TRAV_LEAF : (ref & GD_REF_TWO) ? TRAV_LEAF_TRIS : TRAV_LEAF_TRI1;
     } else {
         t.node = ref;
         t.entry = entry;
@@ -432,7 +435,7 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
 template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES>
 GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
     bool stop;
-    if (t.state == TRAV_LEAF_TRIS) stop = leaf_test_tris<ANY_HIT, COUNT>(sc, r, t.node, t.closest, t.hit_prim, wc);
+    if (t.state != TRAV_LEAF) stop = leaf_test_tris<ANY_HIT, COUNT>(sc, r, t.node, t.state == TRAV_LEAF_TRIS, t.closest, t.hit_prim, wc);
     else stop = leaf_test<ANY_HIT, COUNT, TYPES>(sc, r, t.node, t.closest, t.hit_prim, wc);
     if (stop && ANY_HIT) {
         t.state = TRAV_DONE;

@@ -145,9 +145,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
                 path_begin(P, seed, j, rs0, rd0, rs, rd);
                 b.ray_o[slot] = make_float4(rs.x, rs.y, rs.z, 0);
                 b.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, 0);
-                b.cw[slot] = make_float4(1, 1, 1, 0);
-                b.pc[slot] = make_float4(0, 0, 0, 0);
-                q = slot;
+                q = slot;  // (colorWeight = 1 and pathColor = 0 are not stored: k_shade knows them for segment 0)
             }
         }
         b.queue[0][slot] = q;
@@ -295,7 +293,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
         if (slot != SLOT_INVALID) {
             Ray r; r.o = xyz(b.ray_o[slot]); r.d = xyz(b.ray_d[slot]);
             uint2 h = b.hit[slot];
-            F3 cw = xyz(b.cw[slot]), pathColor = xyz(b.pc[slot]);
+            F3 cw = f3(1, 1, 1), pathColor = f3(0, 0, 0);  // path_tracing.glsl:156-157
+            if (seg > 0) { cw = xyz(b.cw[slot]); pathColor = xyz(b.pc[slot]); }
             F3 rstart = r.o, rdir = r.d;
             segments++;
             const float4 seed = seeds.seed[slot / b.n_slots];
