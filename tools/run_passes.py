@@ -18,7 +18,7 @@ r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
 r.set_primitives(B.make_prims(S.scene_d()))
 r.set_max_path_segments(8)
 r.backend.set_mode(int(os.environ.get('GPUART_MODE', '0')))
-r.backend.set_timing(0)
+r.backend.set_timing(int(os.environ.get('GPUART_TIMING', '0')))
 for _ in range(REPS):
     r.restart_path_tracing(1, K)
     t0 = time.perf_counter()
