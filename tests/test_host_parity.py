@@ -207,3 +207,27 @@ def test_exact_sort_equals_std_sort():
         for threads in (1, 3, 16):
             got = B.sort_permutation(k, threads)
             assert (got == want).all(), "%s, %d threads: %d positions differ" % (name, threads, int((got != want).sum()))
+
+
+def test_gather_api_rejects_bad_calls_without_a_device():
+    """The multi-GPU entry points of include/gpuart_hip.h fail with GPUART_HIP_ERR_ARG (never crash) on NULL contexts and
+    inconsistent shares; the share layout helpers are pure host code (a GPU box is not needed for any of this)."""
+    import ctypes as C
+    L = B.hip_lib()
+    assert L.gpuart_hip_gather(None, 1, C.c_float(1.0), 0, None) == -1
+    assert L.gpuart_hip_gather_all(None, 2, 1, C.c_float(1.0), 0, None) == -1
+    assert L.gpuart_hip_comm_init(None, 2, 0, None) == -1
+    assert L.gpuart_hip_comm_init_all(None, 2) == -1
+    assert L.gpuart_hip_comm_destroy(None) == -1
+    assert L.gpuart_hip_set_share(None, None) == -1
+    g = B.share_of_rank(64, 40, 1, 3)
+    assert (g.y0, g.th, g.band_rows, g.band_stride) == (8, 16, 8, 24)   # bands 1 and 4 of 5
+    assert list(g.rows()) == list(range(8, 16)) + list(range(32, 40))
+    empty = B.share_of_rank(64, 8, 1, 2)                                  # more ranks than bands: an empty share
+    assert empty.th == 0
+    full = np.full((8, 64, 4), -1.0, np.float32)
+    B.scatter_rows_host(empty, np.zeros((0, 64, 4), np.float32), full)
+    assert (full == -1.0).all()
+    bad = B.share_of_rank(64, 40, 0, 1)
+    bad.band_stride = 4                                                   # stride below the band height
+    assert L.gpuart_hip_scatter_rows_host(C.byref(bad), None, None) == -1
