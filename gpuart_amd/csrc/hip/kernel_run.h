@@ -45,7 +45,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     __shared__ float ring_b[GD_RING * BLOCK];
     __shared__ uint32_t ready[RUN_RQ], shadeq[RUN_SQ];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    const uint32_t total = b.n_slots * b.batch;  // a multiple of 64: one chunk = one 8x8 pixel tile of one pass
+    const uint32_t total = b.n_slots * b.batch;  // a multiple of 64: one chunk = 64 consecutive path slots (few pixels x the run's passes)
     const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     const unsigned long long below = (1ull << lane_id()) - 1;
@@ -130,11 +130,11 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                     }
                     F3 rstart = r.o, rdir = r.d;
                     if (COUNT) segments++;
-                    const float4 seed = seeds.seed[s / b.n_slots];
+                    const float4 seed = seeds.seed[slot_pass(b, s)];
                     ShadeResult sr = path_shade(sc, P, seed, seg, r, __uint_as_float(h.x), h.y, rstart, rdir, cw, pathColor);
                     if (sr.broke) {
                         uint32_t lx, ly; F3 rs0, rd0;
-                        slot_pixel(f, s % b.n_slots, lx, ly);
+                        slot_pixel(f, slot_pixel_slot(b, s), lx, ly);
                         camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                         path_commit(f, b, passcolor, s, j, npaths, path_finish(P, rd0, seg, sr.ush, sr.specular, pathColor));
                     } else {
@@ -174,13 +174,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             const uint32_t slot = base + lane_id();
             uint32_t lx, ly;
             uint32_t out = SLOT_INVALID;
-            if (slot_pixel(f, slot % b.n_slots, lx, ly)) {
+            if (slot_pixel(f, slot_pixel_slot(b, slot), lx, ly)) {
                 F3 rs0, rd0, rs, rdd;
                 camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                 if (no_segments) {  // the GLSL loop body never runs: i == 0 and no user-sphere hit
                     path_commit(f, b, passcolor, slot, j, npaths, path_finish(P, rd0, 0, false, false, f3(0, 0, 0)));
                 } else {
-                    path_begin(P, seeds.seed[slot / b.n_slots], j, rs0, rd0, rs, rdd);
+                    path_begin(P, seeds.seed[slot_pass(b, slot)], j, rs0, rd0, rs, rdd);
                     b.ray_o[slot] = make_float4(rs.x, rs.y, rs.z, 0);
                     b.ray_d[slot] = make_float4(rdd.x, rdd.y, rdd.z, 0);
                     out = slot | RUN_F_CLOSEST | RUN_F_FRESH;

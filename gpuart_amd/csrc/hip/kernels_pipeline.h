@@ -28,6 +28,11 @@ namespace {
 
 /// Per-path state of one run of the wavefront pipeline: `batch` passes x `n_slots` pixel slots (pixel slot p: 8x8 tile
 /// p/64 of the tile in row-major tile order, pixel p%64 inside it), all arrays SoA and 16-byte aligned.
+/// Path slot s = pixel slot x batch + pass (slot_pass / slot_pixel_slot below): the passes of a run are INTERLEAVED per
+/// pixel, so that the 64 lanes of a wave hold few pixels x several passes. The camera ray of a pixel differs between
+/// passes only by its sub-pixel jitter, and so does the Sun-shadow ray of its first hit: such lanes visit the same nodes,
+/// the vector L1 serves identical addresses of one instruction with one access, and L1 accesses are what bounds the BVH
+/// queries. Path arithmetic does not depend on the slot order: results are unchanged bit for bit.
 struct PathBuffers {
     float4 *ray_o, *ray_d;   ///< ray of the current / next segment
     uint2 *hit;              ///< closest-hit result of the current segment: (bits(t), primitive index)
@@ -52,6 +57,10 @@ struct SeedBatch {
 #define SLOT_INVALID 0xffffffffu
 
 GD_FN int lane_id() { return threadIdx.x & 63; }
+
+/// Pass (index into the run's RandSeed batch / colour planes) and pixel slot of a path slot.
+GD_FN uint32_t slot_pass(const PathBuffers &b, uint32_t slot) { return slot % b.batch; }
+GD_FN uint32_t slot_pixel_slot(const PathBuffers &b, uint32_t slot) { return slot / b.batch; }
 
 GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned long long *g) {
     // one atomic per counter per wavefront
@@ -106,8 +115,8 @@ GD_FN void path_commit(const Frame &f, const PathBuffers &b, float4 *passcolor, 
     F3 c = (j == 0) ? f3(0.0f + value.x, 0.0f + value.y, 0.0f + value.z) : xyz(b.color[slot]) + value;
     if (j == npaths - 1) {
         uint32_t lx, ly;
-        slot_pixel(f, slot % b.n_slots, lx, ly);
-        passcolor[(size_t)(slot / b.n_slots) * b.tile_pixels + (size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 0);
+        slot_pixel(f, slot_pixel_slot(b, slot), lx, ly);
+        passcolor[(size_t)slot_pass(b, slot) * b.tile_pixels + (size_t)ly * f.tw + lx] = make_float4(c.x, c.y, c.z, 0);
     } else
         b.color[slot] = make_float4(c.x, c.y, c.z, 0);
 }
@@ -133,8 +142,8 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
     const uint32_t total = b.n_slots * b.batch;
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < total; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;
-        bool valid = slot_pixel(f, slot % b.n_slots, lx, ly);
-        const float4 seed = seeds.seed[slot / b.n_slots];
+        bool valid = slot_pixel(f, slot_pixel_slot(b, slot), lx, ly);
+        const float4 seed = seeds.seed[slot_pass(b, slot)];
         uint32_t q = SLOT_INVALID;
         if (valid) {
             F3 rs0, rd0, rs, rd;
@@ -297,11 +306,11 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
             if (seg > 0) { cw = xyz(b.cw[slot]); pathColor = xyz(b.pc[slot]); }
             F3 rstart = r.o, rdir = r.d;
             segments++;
-            const float4 seed = seeds.seed[slot / b.n_slots];
+            const float4 seed = seeds.seed[slot_pass(b, slot)];
             ShadeResult s = path_shade(sc, P, seed, seg, r, __uint_as_float(h.x), h.y, rstart, rdir, cw, pathColor);
             if (s.broke) {
                 uint32_t lx, ly; F3 rs0, rd0;
-                slot_pixel(f, slot % b.n_slots, lx, ly);
+                slot_pixel(f, slot_pixel_slot(b, slot), lx, ly);
                 camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                 path_commit(f, b, accum, slot, j, npaths, path_finish(P, rd0, seg, s.ush, s.specular, pathColor));
             } else {
