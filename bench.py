@@ -305,8 +305,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
 
+    if dist is not None and gather_note is None and not args.verify_gather:
+        be.comm_destroy()  # every rank, while all of them are still alive
     if rank != 0:
         if dist is not None:
+            if args.verify_gather:
+                dist.barrier()  # rank 0 is still checking the gathered frame
             dist.destroy_process_group()
         return
 
@@ -319,6 +323,7 @@ def main():
         same = (got[..., :3].view(np.uint32) == whole[..., :3].view(np.uint32)).all()
         print("verify-gather: gathered %d interleaved row sets == single-rank frame: %s" % (world, bool(same)), file=sys.stderr)
         assert same, "gathered frame differs from the single-rank frame"
+        dist.barrier()
 
     # ---- one pass alone, observed after it (the reference's interactive loop, src/main.cpp:549-599): frame time, not throughput ----
     single_ms = None
