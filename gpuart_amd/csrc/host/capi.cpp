@@ -1,5 +1,7 @@
 // capi.cpp — flat C API over the C++ library (see capi.h).
 #include "capi.h"
+
+#include <thread>
 #include "exact_sort.h"
 
 #include <cstdlib>
@@ -28,17 +30,28 @@ Primitive *make_primitive(const gpuart_prim_desc &d) {
     return nullptr;
 }
 
+/// (Python hands over descriptions, the C++ API wants objects: for large scenes they are made and freed by several threads —
+/// this is harness work, not part of SetPrimitives.)
+template <class F>
+void in_parts(size_t n, F body) {
+    const size_t parts = n >= 65536 ? 8 : 1;
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; k++) th.emplace_back(body, n * k / parts, n * (k + 1) / parts);
+    body(0, n / parts);
+    for (auto &t : th) t.join();
+}
+
 bool make_list(const gpuart_prim_desc *prims, int n, std::vector<Primitive *> &out) {
-    for (int i = 0; i < n; i++) {
-        Primitive *p = make_primitive(prims[i]);
-        if (!p) return false;
-        out.push_back(p);
-    }
+    const size_t base = out.size();
+    out.resize(base + (size_t)n, nullptr);
+    in_parts((size_t)n, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) out[base + i] = make_primitive(prims[i]); });
+    for (size_t i = base; i < out.size(); i++)
+        if (!out[i]) return false;
     return true;
 }
 
 void free_list(std::vector<Primitive *> &v) {
-    for (auto *p : v) delete p;
+    in_parts(v.size(), [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) delete v[i]; });
     v.clear();
 }
 

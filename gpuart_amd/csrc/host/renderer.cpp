@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <chrono>
 #include <iomanip>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -160,6 +162,7 @@ std::ostream &operator<<(std::ostream &os, const ByteCount &bc) {
 
 void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInfo) {
     auto t0 = std::chrono::high_resolution_clock::now();
+    const auto tAll = t0;
     if (printInfo) std::cout << "Constructing BVH tree of " << primitives.size() << " primitives... " << std::flush;
     Tree = BoundingVolumesHierarchy(primitives, 1024, 2);  // reference src/renderer.cpp:454
     if (printInfo) {
@@ -173,6 +176,9 @@ void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInf
     if (!Backend || !Check(gpuart_hip_upload_bvh(Backend, compiled.data(), compiled.size() / RGBA_ELEMS), "uploading the BVH"))
         IsOK = false;
     if (printInfo) std::cout << "Compiled tree occupies " << ByteCount{compiled.size() * sizeof(float)} << "." << std::endl;
+    if (std::getenv("GPUART_HOST_TIMING"))
+        fprintf(stderr, "[gpuart] Renderer::SetPrimitives(%zu primitives): %.1f ms (build + compile + re-layout + upload)\n",
+                primitives.size(), std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - tAll).count());
     ResetPathTracing();
 }
 
