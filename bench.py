@@ -20,8 +20,9 @@ What is counted:
     beside it, with its own rate.
   * `roofline` is a device-level fraction of the resource that binds the BVH queries, the vector L1: its cache accesses of
     all kernels of a pass (TCP_TOTAL_CACHE_ACCESSES_sum, collected by a rocprofv3 child run of THIS invocation on the same
-    passes) / ms_per_step, against one access per cycle and CU (calibrated with tools/ubench; DESIGN.md section 4 for the
-    experiment that names this resource). The VALU-issue view (SQ_INSTS_VALU against 2 cycles per wave64 instruction) and
+    passes) / ms_per_step, against the highest access rate measured on the box (tools/ubench, the product's own node-fetch
+    shape; DESIGN.md section 4 for the experiments that name this resource: extra requests cost their full service time,
+    extra VALU work a third of it). The VALU-issue view (SQ_INSTS_VALU against 2 cycles per wave64 instruction) and
     the HBM view (algorithmic bytes; HBM traffic of the same child runs) are carried as secondary fields: the 8.7 MB tree
     is cache-resident, so algorithmic bytes / time exceeds the HBM peak and is not a fraction of anything.
 Prints ONE JSON line on rank 0.
@@ -48,8 +49,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-L1_PEAK_GACC = 614.4            # 256 CUs x 2.4 GHz x ONE vector-L1 (TCP) cache access per cycle: TCP_TOTAL_CACHE_ACCESSES_sum saturates at
-                                # 5.9-6.7e11/s in every divergent or contiguous load pattern of tools/ubench (profiles/r02/l1_access_calibration.txt)
+L1_PEAK_GACC = 860.0            # the highest vector-L1 (TCP) cache-access rate tools/ubench reaches on the box, with the product's own node
+                                # fetch (2 x dwordx4 + 2 x dwordx3 per lane, every lane its own record): 8.6e11/s, flat from 2 to 8 waves per SIMD
+                                # (profiles/r02/l1_access_calibration.txt). One access per cycle and CU would be 614.4.
 VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling";
                                 # measured on the box: profiles/r02/ubench.txt)
 
@@ -342,9 +344,12 @@ def main():
     roof = {"bound": "l1_accesses", "achieved": None, "peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "frac": None,
             "traffic": None,
             "definition": "TCP_TOTAL_CACHE_ACCESSES_sum of every kernel of a pass / ms_per_step (device level: overlapping launches are not "
-                          "double counted), against 256 CUs x 2.4 GHz x one L1 access per cycle (tools/ubench saturates there in every "
-                          "load pattern). The BVH queries are bound by vector-memory requests: every extra 16-byte fetch per node visit costs "
-                          "+12 % whether it hits L1 or not (profiles/r02/vector_memory_bound.txt)",
+                          "double counted), against the highest L1 access rate measured on the box: 8.6e11/s with the product's own node-fetch "
+                          "shape, flat from 2 to 8 waves per SIMD (tools/ubench; one access per cycle and CU would be 6.14e11 -> "
+                          "frac_of_one_access_per_clock). The BVH queries are bound by vector-memory requests: every extra 16-byte fetch per node "
+                          "visit costs +12 % whether it hits L1 or not - its full service time at that peak rate - while extra VALU work costs a "
+                          "third of its issue time (profiles/r02/vector_memory_bound.txt); the real mix (misses, stores, narrow requests) costs "
+                          "more per access than the calibrating pattern",
             "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s",
                            "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step against 1024 SIMDs x 2.4 GHz / 2 cycles per "
                                          "wave64 VALU instruction"},
@@ -383,6 +388,7 @@ def main():
             roof["l1_misses_to_l2_per_pass"] = tc.get("TCP_TCC_READ_REQ_sum", 0.0) / n
             roof["achieved"] = round(acc / (ms_step * 1e-3) / 1e9, 2)
             roof["frac"] = round(roof["achieved"] / L1_PEAK_GACC, 4)
+            roof["frac_of_one_access_per_clock"] = round(roof["achieved"] / 614.4, 4)
             # HBM traffic: FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B; calibrated for wide streams — our 16-B gathers
             # are uncalibrated, read it as an upper estimate), both counters in KB; counts Infinity-Cache hits too
             fetch = prof["fetch"][0].get("FETCH_SIZE", 0.0) / n

@@ -408,6 +408,27 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     // fetches a ref with a separate, dependent 4-byte load inside the branch that needs it (one more memory
     // round trip per step).
     asm volatile("" : "+v"(q0.w), "+v"(q1.w));
+#if defined(GD_TA_PROBE) || defined(GD_VALU_PROBE)
+    // Measurement hooks (never defined in the product build; tools/ab_build.sh x "-DGD_TA_PROBE=2"): n more 16-byte fetches of
+    // the same record line, resp. n more dependent VALU instructions, per node visit — what tells a request-bound kernel from
+    // an issue-bound one (profiles/r02/vector_memory_bound.txt).
+#ifdef GD_TA_PROBE
+    for (int k = 0; k < GD_TA_PROBE; k++) {
+        const float4 *rp = rec + (k & 3);
+        asm volatile("" : "+v"(rp));
+        float4 dummy = *rp;
+        asm volatile("" ::"v"(dummy.x), "v"(dummy.y), "v"(dummy.z), "v"(dummy.w));
+    }
+#endif
+#ifdef GD_VALU_PROBE
+    {
+        float dummy = q0.x;
+#pragma unroll
+        for (int k = 0; k < GD_VALU_PROBE; k++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(dummy) : "v"(q1.x));
+        asm volatile("" ::"v"(dummy));
+    }
+#endif
+#endif
     float el, eh;
     bool hl, hh;
     // (a version carrying both boxes' arithmetic in packed 2-wide vectors made the compiler turn the validity selects

@@ -13,7 +13,7 @@ for r in csv.DictReader(open("$OUT/x_counter_collection.csv")):
     acc[(r["Kernel_Name"], r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 seen = collections.Counter()
 for (k, d), c in acc.items():
-    if not ("loadcost" in k or "width" in k or "gather" in k): continue
+    if not ("loadcost" in k or "width" in k or "gather" in k or "k_node" in k): continue
     seen[k] += 1
     if seen[k] % 2 == 1: continue   # every measurement launches twice (warm-up, timed): keep the second
     t = dur[(k, d)] * 1e-9

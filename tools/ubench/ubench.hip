@@ -192,6 +192,52 @@ __global__ void __launch_bounds__(64) k_width(const float *__restrict__ recs, ui
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ---- the node fetch as shipped (2 x dwordx4 + 2 x dwordx3 of one 64-byte record) against 3 x dwordx4 of a 48-byte record
+//      + 1 x dwordx2 from a separate array of child references
+template <int SHAPE>
+__global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, const uint2 *__restrict__ refs, uint32_t mask, int iters,
+                                             float *out, unsigned long long *cycles) {
+    uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        const uint32_t r = idx & mask;
+        uint32_t h;
+        if (SHAPE == 0) {
+            const float4 *p = recs + 4 * (size_t)r;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            asm volatile("" : "+v"(a.w), "+v"(b.w));
+            acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + ((c.z + d.x) + (d.y + d.z));
+            h = __float_as_uint(a.w) + __float_as_uint(b.w);
+        } else if (SHAPE == 2) {  // 4 x dwordx3 + 1 x dwordx2, all from one packed 64-byte record
+            struct P3 { float x, y, z; };
+            const char *base = (const char *)(recs + 4 * (size_t)r);
+            const P3 a = *(const P3 *)(base), b = *(const P3 *)(base + 12), c = *(const P3 *)(base + 24), d = *(const P3 *)(base + 36);
+            const uint2 f = *(const uint2 *)(base + 48);
+            acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + ((c.z + d.x) + (d.y + d.z));
+            h = f.x + f.y;
+        } else if (SHAPE == 3) {  // 3 x dwordx4 + 1 x dwordx2 from one 64-byte record, the narrow one kept narrow by its type
+            const float4 *p = recs + 4 * (size_t)r;
+            float4 a = p[0], b = p[1], c = p[2];
+            const uint2 f = *(const uint2 *)((const char *)p + 48);
+            asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w));
+            acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w));
+            h = f.x + f.y;
+        } else {
+            const float4 *p = recs + 3 * (size_t)r;
+            float4 a = p[0], b = p[1], c = p[2];
+            uint2 f = refs[r];
+            asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w));
+            acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w));
+            h = f.x + f.y;
+        }
+        idx = idx * 1664525u + 1013904223u + h;
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 struct Result { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Result> g_results;
 
@@ -305,6 +351,18 @@ int main(int argc, char **argv) {
             timed("fetch32B_2x_dwordx4", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<2><<<n, 64>>>(rf, m, 1024, o, c); });
             timed("fetch64B_8x_dwordx2", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<3><<<n, 64>>>(rf, m, 1024, o, c); });
             timed("fetch64B_16x_dword", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<4><<<n, 64>>>(rf, m, 1024, o, c); });
+        }
+        {
+            uint2 *refs;
+            CHECK(hipMalloc(&refs, nrec * 8));
+            CHECK(hipMemcpy(refs, h.data(), nrec * 8, hipMemcpyHostToDevice));
+            for (int w : {2, 4, 8})
+                timed("node_2x4_2x3_one_record", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<0><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed("node_2x4_2x3_one_record", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<0><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed("node_3x4_plus_refs_x2", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<1><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed("node_4x3_1x2_one_record", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<2><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed("node_3x4_1x2_one_record", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<3><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            CHECK(hipFree(refs));
         }
         CHECK(hipFree(recs));
     }
