@@ -165,8 +165,8 @@ int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float d
 int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, float *full_frame_host);
 
 /* glFlush() equivalent. gpuart_hip_pt_pass may only *collect* a pass: passes with identical parameters are launched
- * together as one run of the pipeline (slot = pass x pixel, up to 16M paths, so that the persistent BVH-query waves take
- * many rays per lane), and up to 8 runs are in flight at once on separate HIP streams (fewer when their path state would
+ * together as one run of the pipeline (path slot = pixel x passes of the run + pass, up to 16M paths, so that the persistent
+ * BVH-query waves take many rays per lane and same-pixel rays of different passes share a wavefront), and up to 8 runs are in flight at once on separate HIP streams (fewer when their path state would
  * exceed 16 GB); results are accumulated strictly in pass order. Everything
  * that observes or changes state (read, export, finish, reset, set_camera, ...) flushes by itself. */
 int gpuart_hip_flush(gpuart_hip_ctx *ctx);
@@ -174,13 +174,17 @@ int gpuart_hip_flush(gpuart_hip_ctx *ctx);
 /* glFinish() equivalent (reference src/main.cpp:564,584). */
 int gpuart_hip_finish(gpuart_hip_ctx *ctx);
 
-/* Execution mode of gpuart_hip_pt_pass / gpuart_hip_render_direct (images are identical in all modes):
- *   0 (default) wavefront pipeline, fast: per segment a persistent BVH-query kernel, a shading kernel
- *               and a Sun-shadow kernel that stops at the first accepted hit and is skipped for surfaces
- *               facing away from the Sun;
- *   1 "reference work": the same pipeline, but every query the reference performs is performed as a
- *               full closest-hit query, and exact counters are kept (gpuart_hip_counters);
- *   2 megakernel: one thread runs a whole path (the first correct version; kept for A/B and cross-checks). */
+/* Execution mode of gpuart_hip_pt_pass / gpuart_hip_render_direct (images are identical, bit for bit, in all modes):
+ *   0 (default) fast: the launch-per-stage wavefront pipeline (per segment a persistent BVH-query launch that also carries
+ *               the previous segment's Sun-shadow queries, and a shading launch; Sun-shadow queries stop at the first accepted
+ *               hit and are skipped for surfaces facing away from the Sun), or — when the whole planned pass sequence is
+ *               small (an interactive frame) — one persistent kernel per run (k_run) without the chain of dependent launches;
+ *   1 "reference work": every query the reference performs is performed as a full closest-hit query, and exact counters
+ *               are kept (gpuart_hip_counters); runs through k_run;
+ *   2 megakernel: one thread runs a whole path (the first correct version; kept for A/B and cross-checks);
+ *   3 the launch pipeline always;   5 k_run always;
+ *   4 as 0, with counters of the work the fast mode really executes (rays, nodes, primitives); runs through k_run.
+ * Direct lighting: 1 one thread per pixel with counters, 2 one thread per pixel, otherwise persistent lanes. */
 int gpuart_hip_set_mode(gpuart_hip_ctx *ctx, int mode);
 int gpuart_hip_counters(gpuart_hip_ctx *ctx, gpuart_counters *out, int reset);
 
