@@ -167,8 +167,8 @@ void plan_runs(gpuart_hip_ctx *c) {
     const double unit = (double)((size_t)2 << 20);
     const size_t min_run = std::max<size_t>(1, c->min_run_paths / c->n_slots);
     size_t want;
-    if (c->planned_passes && (c->mode == 0 || c->mode == 5) && (size_t)c->planned_passes * c->n_slots <= c->small_paths &&
-        c->planned_passes <= c->max_batch) {
+    if (c->planned_passes && (c->mode == 0 || c->mode == 5) && c->planned_passes <= c->max_batch &&
+        (c->small_paths ? c->planned_passes == 1 || (size_t)c->planned_passes * c->n_slots <= c->small_paths : c->mode == 5)) {
         want = c->planned_passes;  // a small sequence is ONE run of the persistent kernel (uses_run_kernel)
     } else if (c->planned_passes) {
         const double u = (double)c->planned_passes * c->n_slots / unit;
@@ -606,12 +606,14 @@ namespace {
 /// Whether a run of `count` passes goes through the persistent run kernel (k_run) rather than the launch pipeline.
 /// Measured on cfg3 (profiles/r02/k_run_vs_pipeline.txt): one pass alone 2.6 vs 3.4 ms, two 1.9 vs 2.0, four 1.66 vs 1.33,
 /// 64 1.02 vs 0.93 ms per pass — k_run has no chain of dependent launches, the pipeline packs lanes better once several
-/// runs overlap. Mode 0 therefore uses k_run when the whole planned sequence is small (an interactive frame).
+/// runs overlap. Mode 0 therefore uses k_run when the whole planned sequence is small (an interactive frame); GPUART_HIP_SMALL_KPATHS=0
+/// turns that off altogether.
 bool uses_run_kernel(const gpuart_hip_ctx *c, size_t count) {
     if (c->mode == 1 || c->mode == 4 || c->mode == 5) return true;
-    if (c->mode != 0) return false;
+    if (c->mode != 0 || !c->small_paths) return false;
     const size_t passes = c->planned_passes ? c->planned_passes : count;
-    return passes * (size_t)c->n_slots <= c->small_paths;
+    // one pass observed alone: k_run at every frame size (4K: 5.7 against 8.2 ms); a short sequence while it is small
+    return passes <= 1 || passes * (size_t)c->n_slots <= c->small_paths;
 }
 
 /// The collected passes [first, first + count) as ONE persistent kernel per path of the pass (k_run, kernel_run.h) on
