@@ -1147,4 +1147,22 @@ int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
     return run_hook(c, n, nullptr, 0, outs, 2, [&](auto &, auto &o) { k_test_cam_rays<<<GRID1(n)>>>(f, o[0], o[1]); });
 }
 
+#ifdef GD_RUN_TIMELINE
+/// diagnostic builds only: the per-wave timeline of the last k_run launch (kernel_run.h), 6 words per wave
+int gpuart_hip_debug_run_timeline(gpuart_hip_ctx *c, unsigned long long *out, size_t waves) {
+    if (!c || !out || waves > 8192) return GPUART_HIP_ERR_ARG;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_timeline), waves * 6 * sizeof(unsigned long long)));
+    return 0;
+}
+/// diagnostic builds only: reads (and clears) the busy-lane histogram of the k_run launches since the last call, 256 words
+int gpuart_hip_debug_run_hist(gpuart_hip_ctx *c, unsigned long long *out) {
+    if (!c || !out) return GPUART_HIP_ERR_ARG;
+    static unsigned long long zero[256];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_hist), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_run_hist), zero, sizeof(zero)));
+    return 0;
+}
+#endif
 }  // extern "C"

@@ -11,10 +11,11 @@
 //   * when 64 paths wait in the shade list the whole wave shades them — path_tracing.glsl:182-233 at full lane
 //     utilisation, as k_shade did — and appends the survivors to the ready list; when the ready list runs short the
 //     wave generates 64 new paths (one 8x8 pixel tile of one pass, path_tracing.glsl:141-175) from a global cursor;
-//   * a path's Sun-shadow query of segment s and its closest-hit query of segment s+1 travel as ONE entry: the lane
-//     that takes it runs the shadow query first (first accepted hit, applies the Sun term), then the closest-hit query
-//     from the same origin. Entries are therefore conserved (one per live path), which bounds the lists:
-//     live paths per wave < 256 (proof at PRODUCE below), ready <= 255, shade <= 127;
+//   * a path's Sun-shadow query of segment s and its closest-hit query of segment s+1 are two entries that two lanes run at
+//     the same time (a path is a chain of up to 5 + 5 queries; run one after the other that chain, not the machine, sets the
+//     time of a single pass: 2.7 instead of 2.1 ms). The path is shaded again when BOTH have finished: the two entries carry
+//     a join flag, a per-slot counter in global memory is 2, whoever decrements it to 0 hands the path to the shade list.
+//     Live paths per wave < 256 (proof at PRODUCE below), so ready <= 510 entries, shade <= 127;
 //   * waves never talk to each other: no device-side termination protocol, no inter-wave visibility question. A wave
 //     ends when the cursor is exhausted and its own lists and lanes are empty.
 //
@@ -25,14 +26,29 @@
 #pragma once
 #include "kernels_pipeline.h"
 
-#define RUN_RQ 256                  ///< capacity of a wave's ready list
+#ifndef RUN_RQ
+#define RUN_RQ 512                  ///< capacity of a wave's ready list (at most two entries per live path)
+#endif
 #define RUN_SQ 128                  ///< capacity of a wave's shade list
 #define RUN_SLOT 0x1fffffffu        ///< entry: path slot (pass x pixel slot)
-#define RUN_F_SHADOW 0x80000000u    ///< entry: run the Sun-shadow query of the segment just shaded first
-#define RUN_F_CLOSEST 0x40000000u   ///< entry: (then) run the closest-hit query of the next segment
+#define RUN_F_SHADOW 0x80000000u    ///< entry: the Sun-shadow query of the segment just shaded (else: the closest-hit query of the next one)
+#define RUN_F_JOIN 0x40000000u      ///< the path's other query is under way too: the last of the two to finish hands the path on
 #define RUN_F_FRESH 0x20000000u     ///< the path has not been shaded yet: segment 0, colorWeight 1, pathColor 0
+#ifndef RUN_SHADE_MIN
+#define RUN_SHADE_MIN 32              ///< idle lanes and an empty ready list: shade this many waiting paths rather than generate new ones
+#endif
+#ifndef RUN_TAIL_DIV
+#define RUN_TAIL_DIV 2                ///< tail: retire / shade once the finished lanes are 1/RUN_TAIL_DIV of the traversing ones
+#endif
 #ifndef GD_RUN_WAVES
-#define GD_RUN_WAVES 5              ///< waves per SIMD: 7.5 KB of LDS per wave -> 21 waves per CU; <= 96 VGPRs
+#define GD_RUN_WAVES 4              ///< waves per SIMD: 8.5 KB of LDS per wave -> 18 waves per CU; <= 128 VGPRs (shading code inside)
+#endif
+
+#ifdef GD_RUN_TIMELINE
+// diagnostic build (tools/run_timeline.py): per wave, the 100 MHz clock at its start, when the cursor ran dry, at its end,
+// and the lane-rounds it spent traversing (active lanes summed over the rounds of the TRAVERSE loop / rounds)
+__device__ unsigned long long g_run_timeline[6 * 8192];
+__device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-time per 25 us bucket
 #endif
 
 namespace {
@@ -59,10 +75,15 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 
     // per-lane query state
     uint32_t ent = SLOT_INVALID;            // the entry this lane works on (slot | flags), SLOT_INVALID: none
-    bool shadow = false;                    // the running query is the entry's Sun-shadow query
     F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0), rdiv = f3(1, 1, 1);
     Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
 
+#ifdef GD_RUN_TIMELINE
+    unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start;
+    __shared__ unsigned tl_hist[2 * 128];
+    tl_hist[lane_id()] = 0; tl_hist[64 + lane_id()] = 0; tl_hist[128 + lane_id()] = 0; tl_hist[192 + lane_id()] = 0;
+    const unsigned long long tl_zero = g_run_hist[2 * 128 - 1];  // the host stores the launch's reference clock there (0: use own start)
+#endif
     for (;;) {
         bool start = false;  // this lane begins a query in this round
         // ---- RETIRE: lanes whose query has finished --------------------------------------------------------------
@@ -70,52 +91,53 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
         {
             const bool done = ent != SLOT_INVALID && t.state == TRAV_DONE;
             const uint32_t s = ent & RUN_SLOT;
-            bool to_shade = false;
+            bool to_shade = false, joins = false;
             if (done) {
-                if (shadow) {
+                if (ent & RUN_F_SHADOW) {
                     // path_tracing.glsl:239-245: the Sun term counts if nothing lies towards the Sun
                     const float4 term = b.sun[s];
                     F3 pathColor = xyz(b.pc[s]);
                     if (sun_visible(P, ro, sun, t.hit_prim)) pathColor = pathColor + xyz(term);
-                    if (ent & RUN_F_CLOSEST) {
-                        b.pc[s] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
-                        ent &= ~RUN_F_SHADOW;
-                        shadow = false;
-                        start = true;  // the next segment's closest-hit query, same origin
-                    } else {
+                    if (__float_as_uint(term.w) & 1u) {
                         path_commit(f, b, passcolor, s, j, npaths, pathColor);  // the path ended with that segment
-                        ent = SLOT_INVALID;
+                    } else {
+                        b.pc[s] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
+                        joins = true;  // its next closest-hit query is under way (or already back)
                     }
                 } else {
                     b.hit[s] = make_uint2(__float_as_uint(t.closest), t.hit_prim);
-                    to_shade = true;
+                    joins = (ent & RUN_F_JOIN) != 0;
+                    to_shade = !joins;
                 }
             }
-            const unsigned long long m = __ballot(to_shade);
-            if (to_shade) {
-                shadeq[n_shade + (uint32_t)__popcll(m & below)] = ent & (RUN_SLOT | RUN_F_FRESH);
-                ent = SLOT_INVALID;
+            if (__ballot(joins)) {
+                // what this lane stored must be in memory before the counter says so (both parties are lanes of this wave)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (joins) to_shade = atomicSub(&b.queue[0][s], 1u) == 1u;
             }
+            const unsigned long long m = __ballot(to_shade);
+            if (to_shade) shadeq[n_shade + (uint32_t)__popcll(m & below)] = ent & (RUN_SLOT | RUN_F_FRESH);
             n_shade += (uint32_t)__popcll(m);
+            if (done) ent = SLOT_INVALID;
         }
         const uint32_t need = (uint32_t)__popcll(__ballot(ent == SLOT_INVALID));
 
         // ---- PRODUCE: shade full batches; generate new paths when the ready list cannot feed the idle lanes ------------
-        // Bound on the lists. Every live path of this wave is in exactly one place: a lane, the ready list or the shade
-        // list (a path's shadow and closest query share one entry). New paths appear only in `generate`, which runs
-        // only while n_ready < need (<= idle lanes) and n_shade < 64: live < busy + idle + 64 = 128 before, < 192 after
-        // a full chunk, and the loop stops as soon as n_ready >= need, so n_ready <= 127 after generating. Shading moves
-        // paths from the shade list to the ready list or ends them. Hence live <= 255 always: ready <= 255, and a shade
-        // batch (<= 64 appends) always fits. The shade list is emptied below 64 here, so RETIRE's <= 64 appends fit 128.
+        // Bound on the lists. Every live path of this wave is represented by one or two entries in lanes / the ready list,
+        // or by one entry of the shade list. New paths appear only in `generate`, which runs only while n_ready < need
+        // (<= idle lanes) and n_shade < 64: fewer than 64 paths in lanes, fewer than 64 in the ready list, fewer than 64
+        // in the shade list, i.e. < 192 before and < 256 after a full chunk. Shading moves paths from the shade list to the
+        // ready list (<= 2 entries each) or ends them. Hence live <= 255 always: ready <= 510 entries, and a shade batch
+        // (<= 128 appends) always fits. The shade list is emptied below 64 here, so RETIRE's <= 64 appends fit 128.
         for (;;) {
             const bool want_rays = n_ready < need;
-            const bool can_shade = n_shade >= BLOCK || (n_shade > 0 && want_rays && exhausted);
+            const bool can_shade = n_shade >= BLOCK || (n_shade > 0 && want_rays && (exhausted || n_shade >= RUN_SHADE_MIN));
             if (can_shade) {
                 // ---- shade up to 64 paths: path_tracing.glsl:182-233, then the loop header of the next segment
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // hit / pc written by other lanes of this wave
                 const uint32_t cnt = min(n_shade, (uint32_t)BLOCK);
                 n_shade -= cnt;
-                uint32_t out = SLOT_INVALID;
+                uint32_t out = SLOT_INVALID, out_sh = SLOT_INVALID;
                 if ((uint32_t)lane_id() < cnt) {
                     const uint32_t e = shadeq[n_shade + lane_id()];
                     const uint32_t s = e & RUN_SLOT;
@@ -144,7 +166,10 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                         if (go_on || sh) {
                             b.ray_o[s] = make_float4(rstart.x, rstart.y, rstart.z, 0);
                             b.pc[s] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
-                            out = s | (sh ? RUN_F_SHADOW : 0u) | (go_on ? RUN_F_CLOSEST : 0u);
+                            const uint32_t join = go_on && sh ? RUN_F_JOIN : 0u;
+                            if (join) b.queue[0][s] = 2u;  // the path is shaded again when both queries are back
+                            if (go_on) out = s | join;
+                            if (sh) out_sh = s | RUN_F_SHADOW | join;
                         } else {
                             path_commit(f, b, passcolor, s, j, npaths, pathColor);  // i >= 1: no special case
                         }
@@ -154,8 +179,12 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                         }
                     }
                 }
-                const unsigned long long m = __ballot(out != SLOT_INVALID);
+                // closest-hit entries below, shadow entries on top: taken newest first, the short shadow queries go first
+                unsigned long long m = __ballot(out != SLOT_INVALID);
                 if (out != SLOT_INVALID) ready[n_ready + (uint32_t)__popcll(m & below)] = out;
+                n_ready += (uint32_t)__popcll(m);
+                m = __ballot(out_sh != SLOT_INVALID);
+                if (out_sh != SLOT_INVALID) ready[n_ready + (uint32_t)__popcll(m & below)] = out_sh;
                 n_ready += (uint32_t)__popcll(m);
                 continue;
             }
@@ -170,7 +199,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 if (lane_id() == 0) base = atomicAdd(cursor, (uint32_t)BLOCK);
                 base = __shfl(base, 0, 64) + static_end;
             }
-            if (base >= total) { exhausted = true; continue; }
+            if (base >= total) {
+                exhausted = true;
+#ifdef GD_RUN_TIMELINE
+                tl_dry = wall_clock64();
+#endif
+                continue;
+            }
             const uint32_t slot = base + lane_id();
             uint32_t lx, ly;
             uint32_t out = SLOT_INVALID;
@@ -183,7 +218,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                     path_begin(P, seeds.seed[slot_pass(b, slot)], j, rs0, rd0, rs, rdd);
                     b.ray_o[slot] = make_float4(rs.x, rs.y, rs.z, 0);
                     b.ray_d[slot] = make_float4(rdd.x, rdd.y, rdd.z, 0);
-                    out = slot | RUN_F_CLOSEST | RUN_F_FRESH;
+                    out = slot | RUN_F_FRESH;
                 }
             }
             const unsigned long long m = __ballot(out != SLOT_INVALID);
@@ -199,14 +234,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             const uint32_t rank = (uint32_t)__popcll(idle & below);
             if (ent == SLOT_INVALID && rank < take) {
                 ent = ready[n_ready - 1 - rank];  // newest first (oldest first measured the same)
-                shadow = (ent & RUN_F_SHADOW) != 0;
                 ro = xyz(b.ray_o[ent & RUN_SLOT]);
                 start = true;
             }
             n_ready -= take;
         }
         if (start) {
-            rd = shadow ? sun : xyz(b.ray_d[ent & RUN_SLOT]);
+            rd = (ent & RUN_F_SHADOW) ? sun : xyz(b.ray_d[ent & RUN_SLOT]);
             rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
             trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
         }
@@ -222,22 +256,41 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 if (t.state & 1) {
                     trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
-                    if (!REFWORK && shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
+                    if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                 }
                 descending = __ballot(t.state == TRAV_DESCEND);
                 at_leaf = __ballot((t.state & 1) != 0);
             }
             const unsigned long long busy = descending | at_leaf;
+#ifdef GD_RUN_TIMELINE
+            tl_lanes += (unsigned long long)__popcll(busy); tl_rounds++;
+            {
+                const unsigned long long now = wall_clock64();
+                const unsigned bucket = (unsigned)min((now - (tl_zero ? tl_zero : tl_start)) / 2500ull, 127ull);
+                if (lane_id() == 0) { tl_hist[bucket] += (unsigned)(now - tl_prev) * (unsigned)__popcll(busy); tl_hist[128 + bucket] += (unsigned)(now - tl_prev); }
+                tl_prev = now;
+            }
+#endif
             if (!busy) break;
             if (64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) {
                 // worth a round of RETIRE / PRODUCE / REFILL if that can put idle lanes back to work: a finished lane
                 // holds a path that goes on, or the lists / the cursor still have something
-                const unsigned long long finished = __ballot(ent != SLOT_INVALID && t.state == TRAV_DONE);
-                if (finished || n_ready || n_shade || !exhausted) break;
+                // In the tail (cursor dry, lists empty) only finished lanes can feed the idle ones, through a shade step during which
+                // the lanes still traversing stand still: wait until the finished lanes are a fair share of those.
+                const uint32_t finished = (uint32_t)__popcll(__ballot(ent != SLOT_INVALID && t.state == TRAV_DONE));
+                if (n_ready || n_shade || !exhausted || finished * RUN_TAIL_DIV >= (uint32_t)__popcll(busy)) break;
             }
         }
     }
     if (COUNT) flush_counters(wc, segments, gcounters);
+#ifdef GD_RUN_TIMELINE
+    if (lane_id() == 0 && blockIdx.x < 8192) {
+        unsigned long long *o = g_run_timeline + 6 * blockIdx.x;
+        o[0] = tl_start; o[1] = tl_dry; o[2] = wall_clock64(); o[3] = tl_lanes; o[4] = tl_rounds;
+        for (int k = 0; k < 256; k++) if (tl_hist[k]) atomicAdd(&g_run_hist[k], (unsigned long long)tl_hist[k]);
+        o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);  // XCC_ID, HW_ID
+    }
+#endif
 }
 
 }  // namespace
