@@ -152,6 +152,17 @@ def sun_direction(az, alt):
     return np.array(list(out), np.float32)
 
 
+def vec3_ops(a, b, s, dtype=np.float32):
+    """Every Vec3 operation of csrc/host/math_types.h once (36 values; gpuart_vec3f_ops / gpuart_vec3d_ops)."""
+    a = np.ascontiguousarray(a, dtype); b = np.ascontiguousarray(b, dtype)
+    out = np.zeros(36, dtype)
+    if dtype == np.float32:
+        host_lib().gpuart_vec3f_ops(_p(a), _p(b), C.c_float(float(s)), _p(out))
+    else:
+        host_lib().gpuart_vec3d_ops(_p(a), _p(b), C.c_double(float(s)), _p(out))
+    return out
+
+
 # ---- device back end (include/gpuart_hip.h) -----------------------------------------------------------
 class TileGeom(C.Structure):
     """gpuart_tile_geom (include/gpuart_hip.h): one rank's share of a frame sharded by rows."""

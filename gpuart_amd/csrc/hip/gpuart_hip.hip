@@ -413,7 +413,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
     c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
-    c->small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 4096, 0, 1 << 20) << 10;
+    c->small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 6400, 0, 1 << 20) << 10;
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -604,8 +604,8 @@ static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
 
 namespace {
 /// Whether a run of `count` passes goes through the persistent run kernel (k_run) rather than the launch pipeline.
-/// Measured on cfg3 (profiles/r02/k_run_vs_pipeline.txt): one pass alone 2.6 vs 3.4 ms, two 1.9 vs 2.0, four 1.66 vs 1.33,
-/// 64 1.02 vs 0.93 ms per pass — k_run has no chain of dependent launches, the pipeline packs lanes better once several
+/// Measured on cfg3 (profiles/r02/k_run_vs_pipeline.txt): one pass alone 2.2 vs 3.4 ms, two 1.65 vs 1.98, three 1.47 vs 1.56, four
+/// 1.36 vs 1.31, 64 1.19 vs 0.93 ms per pass — k_run has no chain of dependent launches, the pipeline packs lanes better once several
 /// runs overlap. Mode 0 therefore uses k_run when the whole planned sequence is small (an interactive frame); GPUART_HIP_SMALL_KPATHS=0
 /// turns that off altogether.
 bool uses_run_kernel(const gpuart_hip_ctx *c, size_t count) {
@@ -1148,11 +1148,11 @@ int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
 }
 
 #ifdef GD_RUN_TIMELINE
-/// diagnostic builds only: the per-wave timeline of the last k_run launch (kernel_run.h), 6 words per wave
+/// diagnostic builds only: the per-wave timeline of the last k_run launch (kernel_run.h), 8 words per wave
 int gpuart_hip_debug_run_timeline(gpuart_hip_ctx *c, unsigned long long *out, size_t waves) {
     if (!c || !out || waves > 8192) return GPUART_HIP_ERR_ARG;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_timeline), waves * 6 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_timeline), waves * 8 * sizeof(unsigned long long)));
     return 0;
 }
 /// diagnostic builds only: reads (and clears) the busy-lane histogram of the k_run launches since the last call, 256 words

@@ -47,7 +47,7 @@
 #ifdef GD_RUN_TIMELINE
 // diagnostic build (tools/run_timeline.py): per wave, the 100 MHz clock at its start, when the cursor ran dry, at its end,
 // and the lane-rounds it spent traversing (active lanes summed over the rounds of the TRAVERSE loop / rounds)
-__device__ unsigned long long g_run_timeline[6 * 8192];
+__device__ unsigned long long g_run_timeline[8 * 8192];
 __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-time per 25 us bucket
 #endif
 
@@ -79,7 +79,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
 
 #ifdef GD_RUN_TIMELINE
-    unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start;
+    unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start, tl_nready = 0, tl_nshade = 0;
     __shared__ unsigned tl_hist[2 * 128];
     tl_hist[lane_id()] = 0; tl_hist[64 + lane_id()] = 0; tl_hist[128 + lane_id()] = 0; tl_hist[192 + lane_id()] = 0;
     const unsigned long long tl_zero = g_run_hist[2 * 128 - 1];  // the host stores the launch's reference clock there (0: use own start)
@@ -264,6 +264,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             const unsigned long long busy = descending | at_leaf;
 #ifdef GD_RUN_TIMELINE
             tl_lanes += (unsigned long long)__popcll(busy); tl_rounds++;
+            if (!exhausted) { tl_nready += n_ready; tl_nshade += n_shade; }
             {
                 const unsigned long long now = wall_clock64();
                 const unsigned bucket = (unsigned)min((now - (tl_zero ? tl_zero : tl_start)) / 2500ull, 127ull);
@@ -285,7 +286,8 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     if (COUNT) flush_counters(wc, segments, gcounters);
 #ifdef GD_RUN_TIMELINE
     if (lane_id() == 0 && blockIdx.x < 8192) {
-        unsigned long long *o = g_run_timeline + 6 * blockIdx.x;
+        unsigned long long *o = g_run_timeline + 8 * blockIdx.x;
+        o[6] = tl_nready; o[7] = tl_nshade;
         o[0] = tl_start; o[1] = tl_dry; o[2] = wall_clock64(); o[3] = tl_lanes; o[4] = tl_rounds;
         for (int k = 0; k < 256; k++) if (tl_hist[k]) atomicAdd(&g_run_hist[k], (unsigned long long)tl_hist[k]);
         o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);  // XCC_ID, HW_ID

@@ -94,6 +94,16 @@ struct gpuart_renderer {
     gpuart_renderer(unsigned w, unsigned h, const Camera &c, int device) : impl(w, h, c, device) {}
 };
 
+namespace {
+template <typename T>
+void vec3_ops(const T av[3], const T bv[3], T s, T out[36]) {
+    const Vec3<T> a(av[0], av[1], av[2]), b(bv[0], bv[1], bv[2]);
+    out[0] = a.length(); out[1] = a.sqrlength(); out[2] = a * b;
+    const Vec3<T> r[11] = {a.normalized(), a ^ b, a + b, a - b, a * s, s * a, a / s, a.vrotx(s), a.vroty(s), a.vrotz(s), -a};
+    for (int i = 0; i < 11; i++) { out[3 + 3 * i] = r[i].x; out[4 + 3 * i] = r[i].y; out[5 + 3 * i] = r[i].z; }
+}
+}  // namespace
+
 extern "C" {
 
 int gpuart_compile_bvh(const gpuart_prim_desc *prims, int n, unsigned maxLevels, unsigned minPrims, float **quads,
@@ -139,6 +149,9 @@ void gpuart_camera_basis(const float pos[3], const float dir[3], const float up[
 void gpuart_sun_direction(float azimuth, float altitude, float out[3]) {
     Renderer::ComputeSunDirection(azimuth, altitude).storeIn(out);
 }
+
+void gpuart_vec3f_ops(const float a[3], const float b[3], float s, float out[36]) { vec3_ops<float>(a, b, s, out); }
+void gpuart_vec3d_ops(const double a[3], const double b[3], double s, double out[36]) { vec3_ops<double>(a, b, s, out); }
 
 gpuart_renderer *gpuart_renderer_create(unsigned width, unsigned height, const float pos[3], const float dir[3],
                                         const float up[3], float fovY, float screenDist, int device) {

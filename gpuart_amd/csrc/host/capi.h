@@ -37,6 +37,11 @@ void gpuart_sort_permutation(const float *keys, size_t n, unsigned threads, uint
 void gpuart_camera_basis(const float pos[3], const float dir[3], const float up[3], float fovY, float screenDist,
                          unsigned width, unsigned height, float out[13]);
 void gpuart_sun_direction(float azimuth, float altitude, float out[3]);
+/// Every Vec3<float> / Vec3<double> operation of math_types.h once (parity hook: tests/golden/host_math.npz holds what the
+/// reference's own src/math_types.h computes): out = {length, sqrlength, a*b} + normalized + a^b + a+b + a-b + a*s + s*a + a/s +
+/// vrotx(s) + vroty(s) + vrotz(s) + (-a).
+void gpuart_vec3f_ops(const float a[3], const float b[3], float s, float out[36]);
+void gpuart_vec3d_ops(const double a[3], const double b[3], double s, double out[36]);
 
 /* ---- gpuart::Renderer ---- */
 gpuart_renderer *gpuart_renderer_create(unsigned width, unsigned height, const float pos[3], const float dir[3],

@@ -231,3 +231,39 @@ def test_gather_api_rejects_bad_calls_without_a_device():
     bad = B.share_of_rank(64, 40, 0, 1)
     bad.band_stride = 4                                                   # stride below the band height
     assert L.gpuart_hip_scatter_rows_host(C.byref(bad), None, None) == -1
+
+
+# ---- host vector arithmetic against the reference's own compiled src/math_types.h ------------------------------------
+# tests/golden/host_math.npz: inputs + outputs of oracle/_ref/libmathref.so (oracle/mathref/mathref.cpp compiled against
+# /root/reference/src/math_types.h where it lies; tests/golden/make_host_golden.py). Pins rows a17 / a19 of SURVEY.md 8(a) as
+# far as they are Vec3 arithmetic: both the product's host library and the oracle must reproduce it bit for bit.
+def _host_math():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_math.npz"))
+
+
+def test_sun_direction_equals_reference_vec3_arithmetic():
+    g = _host_math()
+    got_p = np.stack([B.sun_direction(az, alt) for az, alt in g["sun_in"]])
+    got_o = np.stack([O.sun_direction(az, alt) for az, alt in g["sun_in"]])
+    assert_bits(got_p, g["sun_out"], "product sun direction vs reference math_types.h")
+    assert_bits(got_o, g["sun_out"], "oracle sun direction vs reference math_types.h")
+
+
+def test_camera_basis_equals_reference_vec3_arithmetic():
+    g = _host_math()
+    for name, fn in (("product", B.camera_basis), ("oracle", O.camera)):
+        got = np.stack([fn(c[0:3], c[3:6], c[6:9], float(c[9]), float(c[10]), int(c[11]), int(c[12])) for c in g["cam_in"]])
+        assert_bits(got[:, 0:3], g["cam_in"][:, 0:3], name + " camera position")
+        assert_bits(got[:, 3:13], g["cam_out"], name + " screen basis + pixel size vs reference math_types.h")
+
+
+def test_vec3_operations_equal_reference_math_types():
+    """Every operation of the product's Vec3<float> / Vec3<double> (csrc/host/math_types.h, part of the kept API surface) on
+    the golden inputs, incl. zero vectors (NaN from normalized()), huge and tiny values."""
+    g = _host_math()
+    for dt, tag in ((np.float32, "vec3f"), (np.float64, "vec3d")):
+        a, b, s, exp = g[tag + "_a"], g[tag + "_b"], g[tag + "_s"], g[tag + "_out"]
+        got = np.stack([B.vec3_ops(a[i], b[i], s[i], dt) for i in range(len(a))])
+        ui = np.uint32 if dt == np.float32 else np.uint64
+        same = (got.view(ui) == exp.view(ui)) | (np.isnan(got) & np.isnan(exp))
+        assert same.all(), "%s: %d of %d values differ from the reference's" % (tag, int((~same).sum()), same.size)
