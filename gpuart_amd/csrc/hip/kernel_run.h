@@ -7,15 +7,19 @@
 //
 //   * every wave owns a `ready` list (paths with a BVH query to run) and a `shade` list (paths whose closest-hit query
 //     has finished). Lanes are not tied to paths: a lane that finishes a query hands its path to the shade list and
-//     takes the next entry of the ready list, so all 64 lanes keep traversing (the loop of k_trace);
+//     takes the OLDEST entry of the ready list (a ring), so all 64 lanes keep traversing (the loop of k_trace);
 //   * when 64 paths wait in the shade list the whole wave shades them — path_tracing.glsl:182-233 at full lane
 //     utilisation, as k_shade did — and appends the survivors to the ready list; when the ready list runs short the
 //     wave generates 64 new paths (one 8x8 pixel tile of one pass, path_tracing.glsl:141-175) from a global cursor;
 //   * a path's Sun-shadow query of segment s and its closest-hit query of segment s+1 are two entries that two lanes run at
 //     the same time (a path is a chain of up to 5 + 5 queries; run one after the other that chain, not the machine, sets the
-//     time of a single pass: 2.7 instead of 2.1 ms). The path is shaded again when BOTH have finished: the two entries carry
-//     a join flag, a per-slot counter in global memory is 2, whoever decrements it to 0 hands the path to the shade list.
-//     Live paths per wave < 256 (proof at PRODUCE below), so ready <= 510 entries, shade <= 127;
+//     time of a pass observed alone: 2.9 ms, against 2.2 now). The path is shaded again when BOTH have finished: the two
+//     entries carry a join flag, a per-slot counter in global memory is 2, whoever decrements it to 0 hands the path to the
+//     shade list. Live paths per wave are counted (n_live < 192, proof at PRODUCE below): ready <= 382 entries, shade <= 127;
+//   * what a single pass costs beyond its work is the tail (tools/run_timeline.py): the cursor runs dry after 0.85 ms with the
+//     machine full, and the paths born last still have a chain of up to five segments ahead, ~0.25 ms each while the machine
+//     is loaded; busy lanes then halve every ~0.25 ms. Hence: shade as soon as lanes would idle (RUN_SHADE_MIN), do not stop
+//     the traversing lanes for every single finished one (RUN_TAIL_DIV), never generate ahead of need (RUN_LIVE_MAX);
 //   * waves never talk to each other: no device-side termination protocol, no inter-wave visibility question. A wave
 //     ends when the cursor is exhausted and its own lists and lanes are empty.
 //
@@ -36,6 +40,11 @@
 #define RUN_F_FRESH 0x20000000u     ///< the path has not been shaded yet: segment 0, colorWeight 1, pathColor 0
 #ifndef RUN_SHADE_MIN
 #define RUN_SHADE_MIN 32              ///< idle lanes and an empty ready list: shade this many waiting paths rather than generate new ones
+#endif
+#ifndef RUN_LIVE_MAX
+#define RUN_LIVE_MAX 0                ///< generate ahead while the wave holds at most this many live paths (0: only when lanes would idle).
+                                      ///< Measured (gpurun_out/ab_eager.txt): 128 / 192 / 256 -> 2.19 / 2.40 / 2.68 ms against 2.16 for one pass alone:
+                                      ///< paths waiting in a list do not progress, and the later the cursor runs dry the better it balances the waves
 #endif
 #ifndef RUN_TAIL_DIV
 #define RUN_TAIL_DIV 2                ///< tail: retire / shade once the finished lanes are 1/RUN_TAIL_DIV of the traversing ones
@@ -69,7 +78,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     uint32_t segments = 0;
 
     // wave-uniform bookkeeping
-    uint32_t n_ready = 0, n_shade = 0;
+    uint32_t n_ready = 0, n_shade = 0, r_head = 0, n_live = 0;  // the ready list is a ring: oldest entry at r_head
     bool first_chunk = true, exhausted = false;
     const uint32_t static_end = gridDim.x * BLOCK;  // the first chunk of every wave is static, the cursor starts behind them
 
@@ -91,7 +100,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
         {
             const bool done = ent != SLOT_INVALID && t.state == TRAV_DONE;
             const uint32_t s = ent & RUN_SLOT;
-            bool to_shade = false, joins = false;
+            bool to_shade = false, joins = false, ended = false;
             if (done) {
                 if (ent & RUN_F_SHADOW) {
                     // path_tracing.glsl:239-245: the Sun term counts if nothing lies towards the Sun
@@ -100,6 +109,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                     if (sun_visible(P, ro, sun, t.hit_prim)) pathColor = pathColor + xyz(term);
                     if (__float_as_uint(term.w) & 1u) {
                         path_commit(f, b, passcolor, s, j, npaths, pathColor);  // the path ended with that segment
+                        ended = true;
                     } else {
                         b.pc[s] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
                         joins = true;  // its next closest-hit query is under way (or already back)
@@ -118,17 +128,19 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             const unsigned long long m = __ballot(to_shade);
             if (to_shade) shadeq[n_shade + (uint32_t)__popcll(m & below)] = ent & (RUN_SLOT | RUN_F_FRESH);
             n_shade += (uint32_t)__popcll(m);
+            n_live -= (uint32_t)__popcll(__ballot(ended));
             if (done) ent = SLOT_INVALID;
         }
         const uint32_t need = (uint32_t)__popcll(__ballot(ent == SLOT_INVALID));
 
         // ---- PRODUCE: shade full batches; generate new paths when the ready list cannot feed the idle lanes ------------
-        // Bound on the lists. Every live path of this wave is represented by one or two entries in lanes / the ready list,
-        // or by one entry of the shade list. New paths appear only in `generate`, which runs only while n_ready < need
-        // (<= idle lanes) and n_shade < 64: fewer than 64 paths in lanes, fewer than 64 in the ready list, fewer than 64
-        // in the shade list, i.e. < 192 before and < 256 after a full chunk. Shading moves paths from the shade list to the
-        // ready list (<= 2 entries each) or ends them. Hence live <= 255 always: ready <= 510 entries, and a shade batch
-        // (<= 128 appends) always fits. The shade list is emptied below 64 here, so RETIRE's <= 64 appends fit 128.
+        // Bound on the lists. n_live counts the wave's live paths: +1 per generated path, -1 where a path is committed. A live
+        // path is represented by one or two entries in lanes / the ready list, or by one entry of the shade list. New paths
+        // appear only in `generate`, which (RUN_LIVE_MAX = 0) runs only while n_ready < need (<= idle lanes) and n_shade < 64
+        // (or < RUN_SHADE_MIN with lanes idle): fewer than 64 paths in lanes, fewer than 64 in the ready list, fewer than 64 in
+        // the shade list, i.e. n_live < 192 before and < 256 after a chunk; whatever RUN_LIVE_MAX says, generation stops at
+        // n_live + 64 > 256. Hence ready <= 2 x 256 = 512 entries = RUN_RQ always, and a shade batch (<= 128 appends) fits.
+        // The shade list is emptied below 64 here, so RETIRE's <= 64 appends fit 128.
         for (;;) {
             const bool want_rays = n_ready < need;
             const bool can_shade = n_shade >= BLOCK || (n_shade > 0 && want_rays && (exhausted || n_shade >= RUN_SHADE_MIN));
@@ -138,6 +150,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 const uint32_t cnt = min(n_shade, (uint32_t)BLOCK);
                 n_shade -= cnt;
                 uint32_t out = SLOT_INVALID, out_sh = SLOT_INVALID;
+                bool ended = false;
                 if ((uint32_t)lane_id() < cnt) {
                     const uint32_t e = shadeq[n_shade + lane_id()];
                     const uint32_t s = e & RUN_SLOT;
@@ -159,6 +172,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                         slot_pixel(f, slot_pixel_slot(b, s), lx, ly);
                         camera_ray(f, f.x0 + lx, frame_y(f, ly), rs0, rd0);
                         path_commit(f, b, passcolor, s, j, npaths, path_finish(P, rd0, seg, sr.ush, sr.specular, pathColor));
+                        ended = true;
                     } else {
                         const bool go_on = sr.next == PATH_CONTINUES;
                         const bool sh = sr.want_shadow && (REFWORK || sr.sun_matters);
@@ -172,6 +186,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                             if (sh) out_sh = s | RUN_F_SHADOW | join;
                         } else {
                             path_commit(f, b, passcolor, s, j, npaths, pathColor);  // i >= 1: no special case
+                            ended = true;
                         }
                         if (go_on) {
                             b.ray_d[s] = make_float4(rdir.x, rdir.y, rdir.z, 0);
@@ -179,16 +194,19 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                         }
                     }
                 }
-                // closest-hit entries below, shadow entries on top: taken newest first, the short shadow queries go first
-                unsigned long long m = __ballot(out != SLOT_INVALID);
-                if (out != SLOT_INVALID) ready[n_ready + (uint32_t)__popcll(m & below)] = out;
+                // oldest first: the short shadow queries of a batch go before its closest-hit queries
+                n_live -= (uint32_t)__popcll(__ballot(ended));
+                unsigned long long m = __ballot(out_sh != SLOT_INVALID);
+                if (out_sh != SLOT_INVALID) ready[(r_head + n_ready + (uint32_t)__popcll(m & below)) & (RUN_RQ - 1)] = out_sh;
                 n_ready += (uint32_t)__popcll(m);
-                m = __ballot(out_sh != SLOT_INVALID);
-                if (out_sh != SLOT_INVALID) ready[n_ready + (uint32_t)__popcll(m & below)] = out_sh;
+                m = __ballot(out != SLOT_INVALID);
+                if (out != SLOT_INVALID) ready[(r_head + n_ready + (uint32_t)__popcll(m & below)) & (RUN_RQ - 1)] = out;
                 n_ready += (uint32_t)__popcll(m);
                 continue;
             }
-            if (!want_rays || exhausted) break;
+            // ahead of need while the wave holds few live paths (RUN_LIVE_MAX): the sooner a path is born the sooner its chain of
+            // up to five segments ends; never beyond 256 live paths (<= 512 entries)
+            if (exhausted || n_live + BLOCK > 256u || !(want_rays || n_live + BLOCK <= (uint32_t)RUN_LIVE_MAX)) break;
             // ---- generate 64 paths: the next 8x8 pixel tile of a pass (path_tracing.glsl:141-175)
             uint32_t base;
             if (first_chunk) {
@@ -222,22 +240,24 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 }
             }
             const unsigned long long m = __ballot(out != SLOT_INVALID);
-            if (out != SLOT_INVALID) ready[n_ready + (uint32_t)__popcll(m & below)] = out;
+            if (out != SLOT_INVALID) ready[(r_head + n_ready + (uint32_t)__popcll(m & below)) & (RUN_RQ - 1)] = out;
             n_ready += (uint32_t)__popcll(m);
+            n_live += (uint32_t)__popcll(m);
         }
 
-        // ---- REFILL: idle lanes take the newest entries of the ready list ---------------------------------------------
+        // ---- REFILL: idle lanes take the oldest entries of the ready list ---------------------------------------------
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // rays / lists written by other lanes of this wave
             const unsigned long long idle = __ballot(ent == SLOT_INVALID);
             const uint32_t take = min((uint32_t)__popcll(idle), n_ready);
             const uint32_t rank = (uint32_t)__popcll(idle & below);
             if (ent == SLOT_INVALID && rank < take) {
-                ent = ready[n_ready - 1 - rank];  // newest first (oldest first measured the same)
+                ent = ready[(r_head + rank) & (RUN_RQ - 1)];  // oldest first: with paths generated ahead, the youngest segments go first
                 ro = xyz(b.ray_o[ent & RUN_SLOT]);
                 start = true;
             }
             n_ready -= take;
+            r_head = (r_head + take) & (RUN_RQ - 1);
         }
         if (start) {
             rd = (ent & RUN_F_SHADOW) ? sun : xyz(b.ray_d[ent & RUN_SLOT]);

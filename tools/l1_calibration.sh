@@ -18,7 +18,7 @@ for (k, d), c in acc.items():
     if seen[k] % 2 == 1: continue   # every measurement launches twice (warm-up, timed): keep the second
     t = dur[(k, d)] * 1e-9
     grid = "?"
-    print("%-60s %7.3f ms  TOTAL_ACCESSES %.3e (%.3e /s)  CACHE_ACCESSES %.3e (%.3e /s)  TCC_READ_REQ %.3e" % (
-        k.split("(")[0][-58:], t * 1e3, c.get("TCP_TOTAL_ACCESSES_sum", 0), c.get("TCP_TOTAL_ACCESSES_sum", 0) / t,
+    print("%-44s %7.3f ms  TOTAL_ACCESSES %.3e (%.3e /s)  CACHE_ACCESSES %.3e (%.3e /s)  TCC_READ_REQ %.3e" % (
+        k.split("(")[0][-42:], t * 1e3, c.get("TCP_TOTAL_ACCESSES_sum", 0), c.get("TCP_TOTAL_ACCESSES_sum", 0) / t,
         c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0), c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / t, c.get("TCP_TCC_READ_REQ_sum", 0)))
 PY

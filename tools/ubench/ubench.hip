@@ -16,6 +16,13 @@
 
 #include "device_scene.h"
 
+// Address chains must DEPEND on the loaded data (a traversal step's next address does) without being STEERED by it: with
+// idx' = f(idx, data[idx & mask]) the low bits form one map r -> r' shared by every lane, all lanes fall into its few short cycles
+// within a few hundred steps and the "random" gather turns into a few hundred hot records (round 2's first calibration had
+// that flaw). g_zero is 0 at run time, unknown at compile time: `+ (h & zero)` keeps the dependency and leaves the sequence a
+// full-period LCG per lane.
+__device__ uint32_t g_zero = 0;
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static int g_cus = 256;
@@ -103,6 +110,7 @@ __global__ void __launch_bounds__(64) k_gather(const float4 *__restrict__ recs, 
                                                unsigned long long *cycles) {
     uint32_t idx[CHAINS];
     float acc = 0;
+    const uint32_t zero = g_zero;
     for (int c = 0; c < CHAINS; c++) idx[c] = (blockIdx.x * 64 + threadIdx.x) * 2654435761u + c * 40503u;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
@@ -112,7 +120,7 @@ __global__ void __launch_bounds__(64) k_gather(const float4 *__restrict__ recs, 
             float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
             asm volatile("" : "+v"(q0.w), "+v"(q1.w));
             acc += (q0.x + q1.y) + (q2.z + q3.x);
-            idx[c] = idx[c] * 1664525u + 1013904223u + __float_as_uint(q0.w) + __float_as_uint(q1.w);
+            idx[c] = idx[c] * 1664525u + 1013904223u + ((__float_as_uint(q0.w) + __float_as_uint(q1.w)) & zero);
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -129,7 +137,7 @@ __global__ void __launch_bounds__(64) k_gather(const float4 *__restrict__ recs, 
 template <int PATTERN>
 __global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs, uint32_t mask, int iters, float *out,
                                                  unsigned long long *cycles) {
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x, zero = g_zero;
     uint32_t idx = (blockIdx.x * 64 + lane) * 2654435761u;
     float acc = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -147,7 +155,7 @@ __global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs
         }
         asm volatile("" : "+v"(q[0].w), "+v"(q[1].w), "+v"(q[2].w), "+v"(q[3].w));
         acc += (q[0].x + q[1].y) + (q[2].z + q[3].x);
-        idx = idx * 1664525u + 1013904223u + __float_as_uint(q[0].w) + __float_as_uint(q[1].w) + __float_as_uint(q[2].w) + __float_as_uint(q[3].w);
+        idx = idx * 1664525u + 1013904223u + ((__float_as_uint(q[0].w) + __float_as_uint(q[1].w) + __float_as_uint(q[2].w) + __float_as_uint(q[3].w)) & zero);
         if (PATTERN == 2) idx = (uint32_t)__shfl((int)idx, 0, 64);
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -160,6 +168,7 @@ __global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs
 template <int SHAPE>
 __global__ void __launch_bounds__(64) k_width(const float *__restrict__ recs, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
     uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    const uint32_t zero = g_zero;
     float acc = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(64) k_width(const float *__restrict__ recs, ui
             for (int k = 0; k < 16; k++) { float a = r[k]; asm volatile("" : "+v"(a)); s += a; h += __float_as_uint(a); }
         }
         acc += s;
-        idx = idx * 1664525u + 1013904223u + h;
+        idx = idx * 1664525u + 1013904223u + (h & zero);
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
@@ -198,6 +207,7 @@ template <int SHAPE>
 __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, const uint2 *__restrict__ refs, uint32_t mask, int iters,
                                              float *out, unsigned long long *cycles) {
     uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    const uint32_t zero = g_zero;
     float acc = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
@@ -223,6 +233,31 @@ __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, co
             asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w));
             acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w));
             h = f.x + f.y;
+        } else if (SHAPE == 4 || SHAPE == 5) {  // 3 x dwordx4 and nothing else: a 48-byte record packed at stride 48 (4) or padded to 64 (5)
+            const float4 *p = recs + (SHAPE == 4 ? 3 : 4) * (size_t)r;
+            float4 a = p[0], b = p[1], c = p[2];
+            asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w));
+            acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + (c.z + c.w);
+            h = __float_as_uint(a.w) + __float_as_uint(b.w);
+        } else if (SHAPE == 6) {  // 4 x dwordx4 (all 64 bytes), the next address depending on the first two only (as SHAPE 0)
+            const float4 *p = recs + 4 * (size_t)r;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w), "+v"(d.w));
+            acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + ((c.z + d.x) + (d.y + d.z)) + (c.w + d.w);
+            h = __float_as_uint(a.w) + __float_as_uint(b.w);
+        } else if (SHAPE == 8 || SHAPE == 9) {  // as SHAPE 0 (8) / SHAPE 6 (9), but record r keeps its k-th 16-byte piece in slot (k + r) & 3: one instruction's lanes spread over the 16-byte slots
+            const float4 *p = recs + 4 * (size_t)r;
+            float4 a = p[r & 3], b = p[(r + 1) & 3], c = p[(r + 2) & 3], d = p[(r + 3) & 3];
+            if (SHAPE == 8) asm volatile("" : "+v"(a.w), "+v"(b.w)); else asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w), "+v"(d.w));
+            acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + ((c.z + d.x) + (d.y + d.z));
+            if (SHAPE == 9) acc += c.w + d.w;
+            h = __float_as_uint(a.w) + __float_as_uint(b.w);
+        } else if (SHAPE == 7) {  // 2 x dwordx4 of a 32-byte record
+            const float4 *p = recs + 2 * (size_t)r;
+            float4 a = p[0], b = p[1];
+            asm volatile("" : "+v"(a.w), "+v"(b.w));
+            acc += ((a.x + a.y) + (a.z + b.x)) + (b.y + b.z);
+            h = __float_as_uint(a.w) + __float_as_uint(b.w);
         } else {
             const float4 *p = recs + 3 * (size_t)r;
             float4 a = p[0], b = p[1], c = p[2];
@@ -231,7 +266,7 @@ __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, co
             acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w));
             h = f.x + f.y;
         }
-        idx = idx * 1664525u + 1013904223u + h;
+        idx = idx * 1664525u + 1013904223u + (h & zero);
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
@@ -293,6 +328,8 @@ int main(int argc, char **argv) {
         CHECK(hipDeviceSynchronize());
         CHECK(hipFree(o)); CHECK(hipFree(cy));
     }
+    const bool only_node = getenv("UBENCH_ONLY_NODE") != nullptr;
+    if (!only_node) {
     for (int w : {1, 2, 4, 6, 8}) {
         timed("valu_fma_independent", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_indep<<<n, 64>>>(o, iters, c); });
     }
@@ -328,8 +365,11 @@ int main(int argc, char **argv) {
         }
         CHECK(hipFree(recs));
     }
-    {
-        const size_t nrec = (size_t)1 << 16;  // 4 MB
+    }
+    for (uint32_t log2rec : {8u, 13u, 16u}) {  // 16 KB (vector L1), 512 KB, 4 MB (one XCD's L2)
+        const size_t nrec = (size_t)1 << log2rec;
+        char sz[32]; snprintf(sz, sizeof sz, "_%zuKB", nrec * 64 / 1024);
+        auto nm = [&](const char *base) { static std::string keep; keep = std::string(base) + sz; return keep.c_str(); };
         float4 *recs;
         CHECK(hipMalloc(&recs, nrec * 64));
         std::vector<uint32_t> h(nrec * 16);
@@ -338,30 +378,39 @@ int main(int argc, char **argv) {
         CHECK(hipMemcpy(recs, h.data(), nrec * 64, hipMemcpyHostToDevice));
         const uint32_t m = (uint32_t)nrec - 1;
         for (int w : {2, 6}) {
-            timed("load4x16B_lane_divergent", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<0><<<n, 64>>>(recs, m, 1024, o, c); }, "64 lanes x own 64-B record");
-            timed("load4x16B_quad_cooperative", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<1><<<n, 64>>>(recs, m, 1024, o, c); }, "same bytes, a quad reads one record per instruction");
-            timed("load4x16B_contiguous", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<2><<<n, 64>>>(recs, m, 1024, o, c); }, "1 KB contiguous per instruction");
-            timed("load4x16B_broadcast", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<3><<<n, 64>>>(recs, m, 1024, o, c); }, "all lanes one record");
-            timed("load4x16B_16_lanes", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<4><<<n, 64>>>(recs, m, 1024, o, c); }, "16 active lanes, own records");
+            if (only_node || log2rec != 16u) break;
+            timed(nm("load4x16B_lane_divergent"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<0><<<n, 64>>>(recs, m, 1024, o, c); }, "64 lanes x own 64-B record");
+            timed(nm("load4x16B_quad_cooperative"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<1><<<n, 64>>>(recs, m, 1024, o, c); }, "same bytes, a quad reads one record per instruction");
+            timed(nm("load4x16B_contiguous"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<2><<<n, 64>>>(recs, m, 1024, o, c); }, "1 KB contiguous per instruction");
+            timed(nm("load4x16B_broadcast"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<3><<<n, 64>>>(recs, m, 1024, o, c); }, "all lanes one record");
+            timed(nm("load4x16B_16_lanes"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<4><<<n, 64>>>(recs, m, 1024, o, c); }, "16 active lanes, own records");
         }
         for (int w : {6}) {
+            if (log2rec != 16u) break;
             const float *rf = (const float *)recs;
-            timed("fetch64B_4x_dwordx4", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<0><<<n, 64>>>(rf, m, 1024, o, c); });
-            timed("fetch56B_3x_dwordx4_1x_dwordx2", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<1><<<n, 64>>>(rf, m, 1024, o, c); });
-            timed("fetch32B_2x_dwordx4", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<2><<<n, 64>>>(rf, m, 1024, o, c); });
-            timed("fetch64B_8x_dwordx2", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<3><<<n, 64>>>(rf, m, 1024, o, c); });
-            timed("fetch64B_16x_dword", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<4><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed(nm("fetch64B_4x_dwordx4"), w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<0><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed(nm("fetch56B_3x_dwordx4_1x_dwordx2"), w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<1><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed(nm("fetch32B_2x_dwordx4"), w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<2><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed(nm("fetch64B_8x_dwordx2"), w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<3><<<n, 64>>>(rf, m, 1024, o, c); });
+            timed(nm("fetch64B_16x_dword"), w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_width<4><<<n, 64>>>(rf, m, 1024, o, c); });
         }
         {
             uint2 *refs;
             CHECK(hipMalloc(&refs, nrec * 8));
             CHECK(hipMemcpy(refs, h.data(), nrec * 8, hipMemcpyHostToDevice));
             for (int w : {2, 4, 8})
-                timed("node_2x4_2x3_one_record", w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<0><<<n, 64>>>(recs, refs, m, 1024, o, c); });
-            timed("node_2x4_2x3_one_record", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<0><<<n, 64>>>(recs, refs, m, 1024, o, c); });
-            timed("node_3x4_plus_refs_x2", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<1><<<n, 64>>>(recs, refs, m, 1024, o, c); });
-            timed("node_4x3_1x2_one_record", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<2><<<n, 64>>>(recs, refs, m, 1024, o, c); });
-            timed("node_3x4_1x2_one_record", 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<3><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+                timed(nm("node_2x4_2x3_one_record"), w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<0><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_2x4_2x3_one_record"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<0><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_3x4_plus_refs_x2"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<1><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_4x3_1x2_one_record"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<2><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_3x4_1x2_one_record"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<3><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_3x4_48B_stride48"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<4><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_3x4_48B_stride64"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<5><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_4x4_64B"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<6><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_2x4_2x3_rotated_slots"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<8><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_2x4_2x3_rotated_slots"), 2, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<8><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_4x4_rotated_slots"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<9><<<n, 64>>>(recs, refs, m, 1024, o, c); });
+            timed(nm("node_2x4_32B"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<7><<<n, 64>>>(recs, refs, m, 1024, o, c); });
             CHECK(hipFree(refs));
         }
         CHECK(hipFree(recs));
