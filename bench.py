@@ -53,6 +53,9 @@ L1_PEAK_GACC = 1010.0           # the highest vector-L1 (TCP) cache-access rate 
                                 # (2 x dwordx4 + 2 x dwordx3 per lane, every lane its own record, records resident in the L1): 1.00-1.01e12/s, flat
                                 # from 4 to 8 waves per SIMD; 8.65-8.75e11 when 5-20 % of the accesses miss to L2 (profiles/r02/l1_access_calibration.txt).
                                 # One access per cycle and CU would be 614.4.
+STEP_PEAK_GVISITS = 227.0       # 64 lanes x 3.55e9 wave-steps/s: the rate at which tools/ubench (k_step) performs the product's traversal step — fetch one
+                                # 64-byte record per lane (every lane its own, L1-resident) + the two aabb_entry tests on it — at k_trace's 6 waves per SIMD
+                                # (8 waves: 3.73e9; fetch alone 4.05e9, tests alone 4.87e9: the hardware overlaps them to 1.14 x the slower one)
 VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling";
                                 # measured on the box: profiles/r02/ubench.txt)
 
@@ -354,6 +357,14 @@ def main():
             "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s",
                            "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step against 1024 SIMDs x 2.4 GHz / 2 cycles per "
                                          "wave64 VALU instruction"},
+            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G node visits/s (lane level)",
+                            "achieved": round(exe[1] / elapsed / 1e9, 2), "frac": round(exe[1] / elapsed / 1e9 / STEP_PEAK_GVISITS, 4),
+                            "definition": "node visits the fast mode executes (device counters, mode-4 replay of the same passes) / wall time, against "
+                                          "64 x the rate at which a register-resident micro-benchmark performs the same step on L1-resident records with "
+                                          "every lane on its own record (tools/ubench k_step, profiles/r02/ubench_step.txt). A second opinion beside `frac`: "
+                                          "the pass spends its time on traversal steps at close to the rate the chip can perform them; it is not below 1 by "
+                                          "much because lanes that share a record (the top of the tree, coherent camera rays) are cheaper than the "
+                                          "calibrating pattern, and it ignores leaf tests, shading and path state"},
             "kernel": "k_trace (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
             "kernel_avg_ms": round(avg_kernel_ms, 5), "kernel_launches": launches, "kernel_ms_summed_per_pass": round(kernel_ms / K, 4),
             "kernel_concurrency": round(kernel_ms / (elapsed * 1e3), 3),

@@ -62,6 +62,9 @@ __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-t
 
 namespace {
 
+static_assert((RUN_RQ & (RUN_RQ - 1)) == 0 && RUN_RQ >= 512, "the ready list is a ring indexed modulo RUN_RQ and must hold two entries for each of 256 live paths");
+static_assert(RUN_SQ >= 2 * BLOCK, "RETIRE appends up to 64 entries to a shade list of up to 63");
+
 template <bool COUNT, bool REFWORK, int TYPES>
 __global__ void __launch_bounds__(BLOCK, GD_RUN_WAVES)
 k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j, int npaths, float4 *passcolor, uint4 *spill,

@@ -273,6 +273,51 @@ __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, co
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ---- do the node fetch and the box arithmetic overlap? One traversal step as the product runs it: fetch a record (2 x dwordx4 +
+//      2 x dwordx3, every lane its own L1-resident record), two aabb_entry tests on the fetched boxes. MODE 0: both, 1: fetch only
+//      (the boxes are not tested), 2: tests only (boxes from registers). If the hardware overlaps the two across the waves of a SIMD,
+//      MODE 0 costs max(1, 2); if it cannot, their sum.
+template <int MODE>
+__global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
+    using namespace gd;
+    uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    const uint32_t zero = g_zero;
+    Ray r;
+    r.o = f3(0.1f + threadIdx.x * 0.01f, -3.0f, 1.0f);
+    r.d = f3(0.02f * threadIdx.x - 0.6f, 1.0f, -0.1f);
+    const F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    F3 lo0 = f3(-1, -1, 0), hi0 = f3(1, 1, 2), lo1 = f3(-2, -1, 0), hi1 = f3(0.5f, 1, 3);
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        uint32_t h = 0;
+        if (MODE != 2) {
+            const float4 *p = recs + 4 * (size_t)(idx & mask);
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            asm volatile("" : "+v"(a.w), "+v"(b.w));
+            h = __float_as_uint(a.w) + __float_as_uint(b.w);
+            if (MODE == 0) {  // boxes from the record (random bits scaled into a sane range: the arithmetic is what matters)
+                lo0 = f3(a.x * 1e-9f, a.y * 1e-9f, a.z * 1e-9f); hi0 = f3(b.x * 1e-9f + 1, b.y * 1e-9f + 1, b.z * 1e-9f + 1);
+                lo1 = f3(c.x * 1e-9f, c.y * 1e-9f, c.z * 1e-9f); hi1 = f3(d.x * 1e-9f + 1, d.y * 1e-9f + 1, d.z * 1e-9f + 1);
+            } else {
+                acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + ((c.z + d.x) + (d.y + d.z));
+            }
+        }
+        if (MODE != 1) {
+            float e0, e1;
+            const bool h0 = aabb_entry(r, rdiv, lo0, hi0, e0), h1 = aabb_entry(r, rdiv, lo1, hi1, e1);
+            acc += (h0 ? e0 : 1.0f) + (h1 ? e1 : 2.0f);
+            asm volatile("" : "+v"(lo0.x), "+v"(lo0.y), "+v"(lo0.z), "+v"(hi0.x), "+v"(hi0.y), "+v"(hi0.z), "+v"(acc));
+            asm volatile("" : "+v"(lo1.x), "+v"(lo1.y), "+v"(lo1.z), "+v"(hi1.x), "+v"(hi1.y), "+v"(hi1.z));
+            if (MODE == 0) h += __float_as_uint(acc);  // the next address waits for the tests, as a traversal step's does
+        }
+        idx = idx * 1664525u + 1013904223u + (h & zero);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 struct Result { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Result> g_results;
 
@@ -412,6 +457,13 @@ int main(int argc, char **argv) {
             timed(nm("node_4x4_rotated_slots"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<9><<<n, 64>>>(recs, refs, m, 1024, o, c); });
             timed(nm("node_2x4_32B"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<7><<<n, 64>>>(recs, refs, m, 1024, o, c); });
             CHECK(hipFree(refs));
+        }
+        if (log2rec == 8u) {
+            for (int w : {2, 4, 6, 8}) {
+                timed("step_fetch_and_2_box_tests_16KB", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<0><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed("step_fetch_only_16KB", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<1><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed("step_2_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2><<<n, 64>>>(recs, m, 1024, o, c); });
+            }
         }
         CHECK(hipFree(recs));
     }
