@@ -2,6 +2,7 @@
 // reference src/bvh.cpp:161-222) and re-lays it out as 64-byte two-children records + 48-byte primitive records
 // (DESIGN.md section 3). Host code only; included by gpuart_hip.hip.
 #pragma once
+#include <cmath>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -58,15 +59,17 @@ struct Converter {
         uint32_t ref;
     };
 
-    /// A box that is inverted (min > max on some axis: e.g. a sphere with a negative radius, or the empty scene)
-    /// or holds a NaN can never be hit by the reference's comparisons. The device's box test assumes min <= max,
-    /// so such a box is replaced by a point box far outside anything a ray can reach (its entry parameter
-    /// would exceed the initial `closest` of 1e19, so it is never entered).
-    static void sanitize(Child &c) {
-        bool ok = true;
-        for (int k = 0; k < 3; k++) ok = ok && (c.bmin[k] <= c.bmax[k]);  // false for NaN too
-        if (!ok)
-            for (int k = 0; k < 3; k++) c.bmin[k] = c.bmax[k] = 3.0e+38f;
+    /// A box that is inverted (min > max on some axis: e.g. a sphere with a negative radius, or the empty scene) or holds
+    /// a NaN is irregular: the device's fast box test (med3) assumes min <= max, while the reference's comparisons can
+    /// still hit such a box through the two planes of its one irregular axis. An infinite bound is irregular too: a plane at
+    /// +-inf gives the reference a legitimate candidate with parameter +inf ("intersected", entry stays 1e19), which the
+    /// fast test cannot tell from no candidate. Boxes are uploaded as they are; a tree with an irregular box anywhere makes
+    /// every box test take the comparison form (Scene::exact_boxes, device_scene.h). With finite, ordered bounds the two
+    /// forms agree for every ray, NaN / infinite origins and directions included.
+    bool irregular = false;
+    void note(const Child &c) {
+        for (int k = 0; k < 3; k++)
+            irregular = irregular || !(c.bmin[k] <= c.bmax[k]) || std::isinf(c.bmin[k]) || std::isinf(c.bmax[k]);  // NaN fails <=
     }
 
     /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
@@ -120,7 +123,7 @@ struct Converter {
         if (!node(lo, depth + 1, L, lo_end)) return false;
         if (hi != lo_end) { err = "upper child does not start where the lower subtree ends"; return false; }
         if (!node(hi, depth + 1, H, end)) return false;
-        sanitize(L); sanitize(H);
+        note(L); note(H);
         recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
         recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
         recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], fbits(depth < top_depth ? 1u : 0u));

@@ -35,6 +35,7 @@ struct Scene {
     const float4 *__restrict__ prims;
     float root_min[3], root_max[3];
     uint32_t root_ref;    ///< record index, or GD_REF_LEAF | first primitive
+    uint32_t exact_boxes; ///< some box of the tree is irregular (min > max or NaN on an axis): every box test takes the comparison form
 };
 
 
@@ -175,6 +176,11 @@ GD_FN float triangle_t(float rox, float roy, float roz, float rdx, float rdy, fl
 /// TYPES: bit t set = primitives of type t may occur (the uploader knows which types a scene holds; code for absent
 /// types is not generated, which is worth 15 VGPRs — a fifth wave per SIMD — in the BVH-query kernel).
 #define GD_ALL_TYPES 0xF
+#define GD_EXACT_BOXES 0x10  ///< beside a type mask: the kernel variant for trees with irregular boxes (box tests in comparison form)
+/// How a kernel tests boxes: the fast (med3) form, the exact comparison form, or whichever Scene::exact_boxes asks for
+/// (kernels off the fast path: one wave-uniform branch per step).
+enum { GD_BOXES_FAST = 0, GD_BOXES_EXACT = 1, GD_BOXES_RUNTIME = 2 };
+#define GD_BOXES_OF(TYPES) (((TYPES) & GD_EXACT_BOXES) ? GD_BOXES_EXACT : GD_BOXES_FAST)
 template <int TYPES = GD_ALL_TYPES>
 GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F3 &p, F3 &n, int &ptype) {
     ptype = (int)(__float_as_uint(q0.w) & 3u);
@@ -191,8 +197,12 @@ GD_FN void prim_hit(const Ray &r, float4 q0, float4 q1, float4 q2, float &pos, F
 /// either its plane parameter k (when k >= 0 and the hit point lies within the face, bounds inclusive) or
 /// +inf; the result is the minimum candidate, exactly the running minimum of the reference.
 ///   * `v within [lo,hi]` is evaluated as med3(v, lo, hi) == v, which equals (v >= lo && v <= hi) for every
-///     box with lo <= hi (the uploader replaces inverted / NaN boxes, which the reference can never hit, by an
-///     unreachable point box); +-0 and NaN behave like the two comparisons.
+///     box with lo <= hi; +-0 and NaN in v behave like the two comparisons. It does NOT for an irregular box
+///     (lo > hi or NaN on an axis: a sphere or disc with a negative, infinite or NaN radius, a NaN coordinate):
+///     the reference can still hit such a box through the two planes of its one irregular axis — those faces
+///     only check the other two axes. Trees that hold an irregular box (the uploader sets Scene::exact_boxes) run
+///     every box test in the EXACT form, two comparisons per bound pair, behind a wave-uniform branch; all others
+///     never pay for it.
 ///   * the reference's `rdir.c != 0` guards need no code: with rdiv.c = +-inf the plane parameter is +-inf or
 ///     NaN, and then either `k >= 0` fails or the hit point is +-inf/NaN and fails the face check.
 /// Returns false on a miss; pos = -1 when the origin is inside (inclusive).
@@ -207,7 +217,36 @@ GD_FN float face_candidate(float k, float a0, float a1, float lo_a, float hi_a, 
     return c;
 }
 
+/// The comparison form: IntersectsAABB statement by statement (shaders/bvh_intersection.glsl:229-354), for trees with
+/// irregular boxes — the `rdir.c != 0` guards are real here (a plane of an infinite box reached with k = +inf is a
+/// candidate the guard must be able to veto), a candidate with k >= 1e19 counts as an intersection but leaves pos at
+/// 1e19, and the running minimum keeps the FIRST of +0 / -0 as `if (k < pos)` does.
+GD_FN bool aabb_entry_exact(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos) {
+    const bool inside = (r.o.x >= bmin.x) & (r.o.y >= bmin.y) & (r.o.z >= bmin.z) & (r.o.x <= bmax.x) & (r.o.y <= bmax.y) & (r.o.z <= bmax.z);
+    bool hit = false;
+    float p = 1.0e+19f;
+#define GD_FACE(dc, plane, oc, rdivc, a0, a1, lo_a, hi_a, b0, b1, lo_b, hi_b)                                      \
+    {                                                                                                              \
+        const float k = ((plane) - (oc)) * (rdivc);                                                                \
+        const float a = (a0) + k * (a1), b = (b0) + k * (b1);                                                      \
+        const bool ok = ((dc) != 0) & (k >= 0) & (a >= (lo_a)) & (a <= (hi_a)) & (b >= (lo_b)) & (b <= (hi_b));    \
+        hit |= ok;                                                                                                 \
+        p = (ok & (k < p)) ? k : p;                                                                                \
+    }
+    GD_FACE(r.d.x, bmin.x, r.o.x, rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z)
+    GD_FACE(r.d.x, bmax.x, r.o.x, rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z)
+    GD_FACE(r.d.y, bmin.y, r.o.y, rdiv.y, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z)
+    GD_FACE(r.d.y, bmax.y, r.o.y, rdiv.y, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z)
+    GD_FACE(r.d.z, bmin.z, r.o.z, rdiv.z, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y)
+    GD_FACE(r.d.z, bmax.z, r.o.z, rdiv.z, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y)
+#undef GD_FACE
+    pos = inside ? -1.0f : p;
+    return inside | hit;
+}
+
+template <bool EXACT = false>
 GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos) {
+    if (EXACT) return aabb_entry_exact(r, rdiv, bmin, bmax, pos);
     const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
     const float c0 = face_candidate((bmin.x - r.o.x) * rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
     const float c1 = face_candidate((bmax.x - r.o.x) * rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
@@ -379,6 +418,7 @@ GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc) {
     }
 }
 
+template <int BOXES = GD_BOXES_RUNTIME>
 GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool count) {
     t.closest = 1e+19f;
     t.hit_prim = GD_NO_PRIM;
@@ -390,17 +430,21 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
     // inside the scene's box) are "hit, entry -1" by the inclusive inside test alone; the six face tests are only run
     // when some lane of the wave starts outside.
     const F3 bmin = f3(sc.root_min[0], sc.root_min[1], sc.root_min[2]), bmax = f3(sc.root_max[0], sc.root_max[1], sc.root_max[2]);
-    const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
     float entry = -1.0f;
     bool hit = true;
-    if (__ballot(!inside) != 0) hit = aabb_entry(r, rdiv, bmin, bmax, entry);
+    if (BOXES == GD_BOXES_EXACT || (BOXES == GD_BOXES_RUNTIME && sc.exact_boxes)) {
+        hit = aabb_entry<true>(r, rdiv, bmin, bmax, entry);
+    } else {
+        const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
+        if (__ballot(!inside) != 0) hit = aabb_entry(r, rdiv, bmin, bmax, entry);
+    }
     if (hit) trav_enter(t, sc.root_ref, entry);  // entry > 1e19 cannot happen
     else t.state = TRAV_DONE;
 }
 
 /// One interior-node visit: fetch its record, test both children's boxes, descend / stack / pop.
 /// Precondition: state == DESCEND.
-template <bool COUNT>
+template <bool COUNT, int BOXES = GD_BOXES_RUNTIME>
 GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc) {
     const float4 *rec = sc.recs + 4 * (size_t)t.node;
     float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
@@ -433,8 +477,13 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     bool hl, hh;
     // (a version carrying both boxes' arithmetic in packed 2-wide vectors made the compiler turn the validity selects
     // into scalar mask logic and ran 17 % slower — tools/ab.py)
-    hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
-    hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
+    if (BOXES == GD_BOXES_EXACT || (BOXES == GD_BOXES_RUNTIME && sc.exact_boxes)) {  // trees with an irregular box (wild input) only
+        hl = aabb_entry<true>(r, rdiv, xyz(q0), xyz(q1), el);
+        hh = aabb_entry<true>(r, rdiv, xyz(q2), xyz(q3), eh);
+    } else {
+        hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
+        hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
+    }
     if (COUNT) {
         wc->nodes++;  // the lower child's box test (the upper one is counted when the reference reaches it)
         wc->steps++;

@@ -119,6 +119,7 @@ struct gpuart_hip_ctx {
     uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
+    uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box (converter.h): box tests take the comparison form
     uint32_t max_depth = 0;
     float4 *d_direct = nullptr, *d_accum = nullptr;
     size_t tile_pixels = 0;
@@ -287,6 +288,7 @@ Scene scene_of(const gpuart_hip_ctx *c) {
     s.recs = c->d_recs;
     memcpy(s.root_min, c->root_min, 12); memcpy(s.root_max, c->root_max, 12);
     s.root_ref = c->root_ref;
+    s.exact_boxes = c->exact_boxes;
     s.prims = c->d_prims;
     return s;
 }
@@ -496,7 +498,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     Converter::Child root;
     size_t tree_end = 0;
     if (!cv.node(0, 0, root, tree_end)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
-    Converter::sanitize(root);
+    cv.note(root);
     int r;
     if ((r = gpuart_hip_flush(c))) return r;
     if ((r = drain(c))) return r;
@@ -504,6 +506,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
     c->root_ref = root.ref;
+    c->exact_boxes = cv.irregular ? 1u : 0u;
     c->type_mask = cv.type_mask;
     c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
@@ -549,8 +552,9 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
         if (!c->d_cursor) HIP_TRY(hipMalloc(&c->d_cursor, 64));
         HIP_TRY(hipMemsetAsync(c->d_cursor, 0, sizeof(uint32_t), c->stream));
         const dim3 pgrid(c->direct_waves);  // alone on the GPU: 16 waves per CU measured best
-        const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;
-        if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
+        const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;
+        if (c->exact_boxes) k_direct_persistent<GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
+        else if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
         else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
     }
     HIP_TRY(hipGetLastError());
@@ -627,7 +631,8 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     for (size_t k = 0; k < count; k++) seeds.seed[k] = c->pend_seeds[first + k];
     if (!l.run_cursor) HIP_TRY(hipMalloc(&l.run_cursor, 64));
     const PathBuffers &b = l.pb;
-    const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
+    const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
+    const bool exact = c->exact_boxes != 0;  // a tree with irregular boxes: the kernel variants with comparison-form box tests
     const uint32_t chunks = b.n_slots * b.batch / BLOCK;
     const dim3 grid(std::min<uint32_t>(c->run_waves, std::max<uint32_t>(1, chunks)));
     TimedLaunch t;
@@ -637,10 +642,13 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
         TimedLaunch tt;
         HIP_TRY(hipMemsetAsync(l.run_cursor, 0, sizeof(uint32_t), l.main));
         if (c->timing_level >= 2 && (r = begin_timed(c, tt, 1, l.main))) return r;
-        if (c->mode == 1) k_run<true, true, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        if (c->mode == 1 && exact) k_run<true, true, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->mode == 1) k_run<true, true, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (c->mode == 4 && flat_only) k_run<true, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->mode == 4 && exact) k_run<true, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (c->mode == 4) k_run<true, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (flat_only) k_run<false, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (exact) k_run<false, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else k_run<false, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         HIP_TRY(hipGetLastError());
         if (c->timing_level >= 2 && (r = end_timed(c, tt, l.main))) return r;
@@ -672,7 +680,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     for (size_t k = 0; k < count; k++) seeds.seed[k] = c->pend_seeds[first + k];
     if ((r = ensure_segment_counters(c, l, nseg))) return r;
     const PathBuffers &b = l.pb;
-    const bool flat_only = c->lean_kernels && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
+    const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->shade_waves, b.n_slots * b.batch / BLOCK));  // k_gen / k_shade: grid-stride loops
@@ -685,6 +693,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         int rr;
         if (detail && (rr = begin_timed(c, tt, 1, l.main))) return rr;
         if (flat_only) k_trace<false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+        else if (c->exact_boxes) k_trace<false, GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         else k_trace<false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         if (detail && (rr = end_timed(c, tt, l.main))) return rr;
         return 0;

@@ -265,13 +265,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
         if (start) {
             rd = (ent & RUN_F_SHADOW) ? sun : xyz(b.ray_d[ent & RUN_SLOT]);
             rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-            trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
+            trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
         }
         if (__ballot(ent != SLOT_INVALID) == 0) break;  // nothing in flight; PRODUCE could not make anything: all done
 
         // ---- TRAVERSE until enough lanes have finished (a lane without an entry is in state DONE) ---------------------
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);

@@ -230,7 +230,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                     ro = xyz(b.ray_o[s]);
                     rd = sh ? sun : xyz(b.ray_d[s]);
                     rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                    trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
+                    trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
                 }
             }
             chunk_next += take;
@@ -243,7 +243,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         }
         // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             // leaves are tested once 1/leaf_share of the lanes that still have a ray wait at one (at most leaf_lanes):
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
     auto start_query = [&](F3 o, F3 d) {
         ro = o; rd = d;
         rdiv = f3(1 / d.x, 1 / d.y, 1 / d.z);
-        trav_init(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
+        trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
     };
 
     for (;;) {
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
         }
         // ---- traverse until enough lanes have an answer (a lane without a pixel is in state DONE)
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<false>(sc, Ray{ro, rd}, rdiv, t, st, nullptr);
+            if (t.state == TRAV_DESCEND) trav_step_box<false, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, nullptr);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);

@@ -53,7 +53,12 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
     if (i >= n) return;
     Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
     float pos;
-    bool h = aabb_entry(r, f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z), xyz(bmin[i]), xyz(bmax[i]), pos);
+    const F3 lo = xyz(bmin[i]), hi = xyz(bmax[i]), rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    // what the uploader decides per tree (converter.h): ordered AND finite bounds take the fast form
+    const float big = 3.4028234663852886e+38f;
+    const bool regular = (lo.x <= hi.x) & (lo.y <= hi.y) & (lo.z <= hi.z) & (fabsf(lo.x) <= big) & (fabsf(lo.y) <= big) & (fabsf(lo.z) <= big) &
+                         (fabsf(hi.x) <= big) & (fabsf(hi.y) <= big) & (fabsf(hi.z) <= big);
+    bool h = regular ? aabb_entry(r, rdiv, lo, hi, pos) : aabb_entry<true>(r, rdiv, lo, hi, pos);
     out[i] = make_float4(h ? 1.0f : 0.0f, h ? pos : 0.0f, 0, 0);
 }
 template <bool ANY>

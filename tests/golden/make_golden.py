@@ -227,6 +227,56 @@ def gen_aabb(gl):
     save("aabb", rs=rs, rd=rd, bmin=lo, bmax=hi, out=np.concatenate(outs)[:, :2].copy())
 
 
+def gen_aabb_irregular(gl):
+    """IntersectsAABB on boxes the build can produce from wild primitives: one axis inverted (a sphere / disc with a negative
+    or infinite radius), NaN or infinite bounds, and rays with zero, infinite or NaN components. The reference can hit a box
+    with ONE irregular axis through that axis's two planes (those faces check only the other two axes), and a plane at +-inf
+    counts as an intersection that leaves the entry at 1e19."""
+    rng = np.random.RandomState(4242)
+    n = 4096
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    lo = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    hi = (lo + rng.uniform(0, 1.5, (n, 3))).astype(np.float32)
+    cen = (lo + hi) / 2
+    rs, rd = rays_towards(rng, n, cen, (hi - lo) * 0.7 + 0.02)
+    ax = rng.randint(0, 3, n)
+    I = np.arange(n)
+    k = I % 16
+    # one irregular axis, by kind
+    sw = k == 0; lo[sw, ax[sw]], hi[sw, ax[sw]] = hi[sw, ax[sw]].copy(), lo[sw, ax[sw]].copy()      # inverted, finite
+    m = k == 1; lo[m, ax[m]] = np.float32(9.9e30); hi[m, ax[m]] = np.float32(-9.9e30)               # the build's initial values
+    m = k == 2; lo[m, ax[m]] = inf; hi[m, ax[m]] = -inf                                             # c - (-inf), c + (-inf)
+    m = k == 3; lo[m, ax[m]] = nan
+    m = k == 4; hi[m, ax[m]] = nan
+    m = k == 5; lo[m, ax[m]] = nan; hi[m, ax[m]] = nan
+    m = k == 6; lo[m, ax[m]] = -inf                                                                 # regular but infinite
+    m = k == 7; hi[m, ax[m]] = inf
+    m = k == 8; lo[m, ax[m]] = -inf; hi[m, ax[m]] = inf
+    m = k == 9; lo[m] = -inf; hi[m] = inf; hi[m, ax[m]] = lo[m, ax[m]] = np.float32(1.5)            # an infinite plate
+    m = k == 10; lo[m] = -inf; hi[m] = inf; lo[m, ax[m]] = np.float32(9.9e30); hi[m, ax[m]] = np.float32(-9.9e30)  # the box of seed 42874's leaf
+    m = k == 11; lo[m] = -inf; hi[m] = -inf                                                         # a point at -inf
+    m = k == 12; a2 = (ax[m] + 1) % 3; lo[m, ax[m]] = inf; hi[m, ax[m]] = -inf; lo[m, a2] = nan     # two irregular axes: never hit
+    m = k == 13; lo[m, ax[m]] = -inf; hi[m, ax[m]] = -inf
+    m = k == 14; lo[m, ax[m]] = np.float32(1e30); hi[m, ax[m]] = inf
+    # k == 15: regular boxes, wild rays only
+    j = (I // 16) % 8
+    m = j == 1; rd[m, ax[m]] = 0
+    m = j == 2; rd[m, (ax[m] + 1) % 3] = 0
+    m = j == 3; rs[m, ax[m]] = inf
+    m = j == 4; rs[m, (ax[m] + 2) % 3] = nan
+    m = j == 5; rd[m, ax[m]] = inf
+    m = j == 6; rd[m, ax[m]] = np.float32(1e30)
+    m = j == 7; rs[m, ax[m]] = np.float32(-1e30)
+    boxes = np.zeros((2 * n, 4), np.float32)
+    boxes[0::2, :3] = lo
+    boxes[1::2, :3] = hi
+    o, = glref.run_probe(gl, "float pos; bool h = IntersectsAABB(i0.xyz, i1.xyz, 1/i1.xyz, BVH, 2*int(gl_FragCoord.x), pos);"
+                         "O0 = vec4(h ? 1.0 : 0.0, h ? pos : 0.0, 0, 0);",
+                         GEOM + ["bvh_intersection.glsl"], [pad4(rs), pad4(rd)], 1, bvh=boxes, decls=D_AABB)
+    print("aabb_irregular: %d of %d boxes hit" % (int((o[:, 0] > 0).sum()), n))
+    save("aabb_irregular", rs=rs, rd=rd, bmin=lo, bmax=hi, out=o[:, :2].copy())
+
+
 def gen_sky(gl):
     rng = np.random.RandomState(19)
     n = 4096
@@ -529,7 +579,7 @@ def gen_cluster_tree(gl):
 
 
 SECTIONS = dict(scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

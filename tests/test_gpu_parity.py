@@ -118,6 +118,28 @@ def test_aabb(be):
     assert_bits(be.test_aabb(pad4(g["rs"]), pad4(g["rd"]), pad4(g["bmin"]), pad4(g["bmax"]))[:, :2], g["out"], "AABB")
 
 
+def test_aabb_irregular_boxes(be):
+    """The box test on irregular boxes (inverted / NaN / infinite axis; what wild primitives make of a node box) against the
+    reference's IntersectsAABB on llvmpipe. The fast med3 form is wrong for these — the reference can hit a box through the
+    planes of its one irregular axis —, so a tree that holds one runs the comparison form (Scene::exact_boxes); the hook
+    decides per box as the uploader does per tree."""
+    g = golden("aabb_irregular")
+    assert_bits(be.test_aabb(pad4(g["rs"]), pad4(g["rd"]), pad4(g["bmin"]), pad4(g["bmax"]))[:, :2], g["out"], "AABB, irregular boxes")
+
+
+def test_wild_scene_with_a_box_hit_through_its_irregular_axis():
+    """Wild case 42874 of tests/fuzz_parity.py (found by the round-2 soak; 1 of 14 500 cases): a disc with radius -inf leaves
+    its leaf with the box x, z in [-inf, inf], y in [9.9e30, -9.9e30]; the reference enters it through the y planes (entry
+    clamped to 1e19) and hits the infinite disc. All three pipelines must agree with the oracle (== reference GLSL here:
+    tests/golden/soak_oracle_vs_reference.py --wild 42874 1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "--wild", "42874", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "1 scenes, 0 with differences" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_sky(be, k):
     g = golden("sky_%d" % k)

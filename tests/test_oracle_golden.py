@@ -83,6 +83,19 @@ def test_aabb():
     assert_bits(O.aabb(pad4(g["rs"]), pad4(g["rd"]), pad4(g["bmin"]), pad4(g["bmax"]))[:, :2], g["out"], "IntersectsAABB")
 
 
+def test_aabb_irregular_boxes():
+    """Boxes with an inverted, NaN or infinite axis and rays with zero / infinite / NaN components, against the reference's
+    IntersectsAABB on llvmpipe (tests/golden/make_golden.py aabb_irregular): a box with ONE irregular axis can be hit through
+    that axis's planes, a plane at +-inf is an intersection that leaves the entry at 1e19."""
+    g = golden("aabb_irregular")
+    assert_bits(O.aabb(pad4(g["rs"]), pad4(g["rd"]), pad4(g["bmin"]), pad4(g["bmax"]))[:, :2], g["out"], "IntersectsAABB, irregular boxes")
+    hit = g["out"][:, 0] > 0
+    lo, hi = g["bmin"], g["bmax"]
+    one_bad = (~(lo <= hi)).sum(1) == 1
+    assert (hit & one_bad).sum() > 50, "the fixture must contain hits through the planes of a single irregular axis"
+
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_sky(k):
     g = golden("sky_%d" % k)

@@ -45,6 +45,30 @@ __global__ void __launch_bounds__(64) k_valu_indep(float *out, int iters, unsign
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
+// the same with 128 v_fma_f32 (or v_add_f32 / v_mul_f32 in their 4-byte VOP2 encoding) between two loop branches: is the 16-instruction
+// loop's rate the VALU's or the loop's?
+template <int OP>
+__global__ void __launch_bounds__(64) k_valu_long(float *out, int iters, unsigned long long *cycles) {
+    float a[16];
+    for (int i = 0; i < 16; i++) a[i] = threadIdx.x * 0.001f + i;
+    float b = 1.0000001f, c = 1e-9f;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                else if (OP == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int i = 0; i < 16; i++) s += a[i];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
 __global__ void __launch_bounds__(64) k_valu_dep(float *out, int iters, unsigned long long *cycles) {
     float a = threadIdx.x * 0.001f;
     float b = 1.0000001f, c = 1e-9f;
@@ -377,6 +401,11 @@ int main(int argc, char **argv) {
     if (!only_node) {
     for (int w : {1, 2, 4, 6, 8}) {
         timed("valu_fma_independent", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_indep<<<n, 64>>>(o, iters, c); });
+    }
+    for (int w : {2, 4, 6, 8}) {
+        timed("valu_fma_independent_unrolled128", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_long<0><<<n, 64>>>(o, iters, c); });
+        timed("valu_add_vop2_unrolled128", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_long<1><<<n, 64>>>(o, iters, c); });
+        timed("valu_mul_vop2_unrolled128", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_long<2><<<n, 64>>>(o, iters, c); });
     }
     for (int w : {1, 2, 4, 6, 8}) {
         timed("valu_fma_dependent", w, iters * 16.0, "wave-instr", [&](int n, float *o, unsigned long long *c) { k_valu_dep<<<n, 64>>>(o, iters, c); });
