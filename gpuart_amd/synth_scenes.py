@@ -171,6 +171,43 @@ def random_case(seed):
                 max_segments=int(rs.choice([1, 3, 5, 8])), npaths=int(rs.choice([1, 1, 2])), passes=3)
 
 
+# second class of hostile numbers (--wild2): sign flips of ordinary values (negative radii), the reference's own magic
+# numbers (closestPos / IntersectsAABB start at 1e19, VISIBILITY_OFFSET 1e-4, the 1e-8 / 1e-10 determinant cut-offs), the float
+# range's ends, denormals (llvmpipe and the device flush them), and camera / user-sphere / Sun parameters out of the ordinary
+WILD2 = [-0.3, -1.0, -0.05, 1e19, -1e19, 0.99e19, 1e-4, -1e-4, 1e-8, 1e-10, 3.4028234e38, -3.4028234e38, 1.17549435e-38,
+         1e-39, 1e-45, -1e-45, 1e10, -1e10, 1e15, 0.5, 1.0]
+
+
+def random_wild2_case(seed):
+    case = random_case(seed)
+    rs = np.random.RandomState(2000003 + seed)
+    prims = []
+    for t, vals in case["prims"]:
+        vals = [f32(v) for v in vals]
+        if rs.rand() < 0.3:
+            for _ in range(int(rs.randint(1, 4))):
+                k = int(rs.randint(len(vals)))
+                vals[k] = f32(-vals[k]) if rs.rand() < 0.3 else f32(WILD2[int(rs.randint(len(WILD2)))])
+        prims.append((t, vals))
+    case["prims"] = prims
+    if rs.rand() < 0.3:  # an odd camera: far away, on a primitive plane, looking straight along an axis, huge / tiny screen distance
+        cam = dict(case["cam"])
+        pick = int(rs.randint(5))
+        if pick == 0: cam["pos"] = tuple(float(f32(x * 1e6)) for x in cam["pos"])
+        elif pick == 1: cam["pos"] = (cam["pos"][0], cam["pos"][1], 0.0)
+        elif pick == 2: cam["dir"] = (0.0, 0.0, -1.0); cam["up"] = (0.0, 1.0, 0.0)
+        elif pick == 3: cam["screen_dist"] = float(f32(rs.choice([1e-6, 1e6, 1e19])))
+        else: cam["fov_y"] = float(f32(rs.choice([0.001, 179.9, 1.0])))
+        case["cam"] = cam
+    if rs.rand() < 0.3:
+        us = list(case["user_sphere"])
+        us[int(rs.randint(4))] = float(f32(WILD2[int(rs.randint(len(WILD2)))]))
+        case["user_sphere"] = tuple(us)
+    if rs.rand() < 0.2:
+        case["sun_alt"] = float(f32(rs.choice([0.0, -0.3, 1.5707964, 3.0, 1e-6])))
+    return case
+
+
 def random_wild_case(seed):
     """random_case(seed) with hostile numbers: some primitive coordinates replaced by NaN, +-inf, +-1e30, +-1e-30 or -0
     (tests/fuzz_parity.py --wild, tests/golden/soak_oracle_vs_reference.py --wild). The reference's comparisons decide what

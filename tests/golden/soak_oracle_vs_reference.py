@@ -18,6 +18,9 @@ from oracle.glref import glref  # noqa: E402
 WILD = "--wild" in sys.argv
 if WILD:
     sys.argv.remove("--wild")
+WILD2 = "--wild2" in sys.argv  # the second class of hostile numbers (gpuart_amd.synth_scenes.random_wild2_case)
+if WILD2:
+    sys.argv.remove("--wild2")
 
 
 def main():
@@ -26,7 +29,7 @@ def main():
     gl = glref.GLRef()
     progs, bad = {}, 0
     for seed in range(first, first + count):
-        case = S.random_wild_case(seed) if WILD else S.random_case(seed)
+        case = S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
         tree, _ = O.build_bvh(case["prims"])
         ms = case["max_segments"]
         if ms not in progs:

@@ -753,7 +753,7 @@ def test_full_size_frame_vs_reference_checksums(B, be, O, sc, tag, mode):
         be.set_mode(0)
 
 
-@pytest.mark.parametrize("wild", [False, True])
+@pytest.mark.parametrize("wild", [False, True, "wild2"])
 def test_random_scenes_soak(wild):
     """tests/fuzz_parity.py: 60 random scenes of all four primitive types incl. degenerate ones (zero radii, zero-area
     and axis-aligned triangles, exact duplicates, cylinders), random cameras, user-sphere modes, Sun on/off, depths 1-8,
@@ -764,7 +764,9 @@ def test_random_scenes_soak(wild):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_parity.py")] + (["--wild"] if wild else []) + ["0", "60"]
+    # "wild2": the second class of hostile numbers (negative radii, the reference's magic numbers 1e19 / 1e-4 / 1e-8 / 1e-10, the
+    # ends of the float range, denormals, odd cameras / user spheres / Sun altitudes; 8 000 cases of it found no difference)
+    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_parity.py")] + (["--wild2"] if wild == "wild2" else ["--wild"] if wild else []) + ["0", "60"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60 scenes, 0 with differences" in r.stdout
