@@ -81,6 +81,19 @@ def test_bvh_ties_and_duplicates():
     assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("flavour", ["plain", "wild", "wild2"])
+def test_bvh_bytes_equal_oracle_on_random_and_hostile_scenes(flavour):
+    """The product's host build (Subdivide / Compile / StoreIntoBVH) against the oracle's on the cases of the parity soaks,
+    hostile numbers included (NaN / +-inf / negative radii / magic numbers in the coordinates: NaN keys in the sort, inverted
+    and infinite boxes, NaN payload bits): byte for byte. (4 500 cases of the same loop found no difference.)"""
+    fn = {"plain": S.random_case, "wild": S.random_wild_case, "wild2": S.random_wild2_case}[flavour]
+    for seed in range(300):
+        prims = fn(seed)["prims"]
+        a, da = B.compile_bvh(prims)
+        b, db = O.build_bvh(prims)
+        assert da == db and a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all(), "%s case %d" % (flavour, seed)
+
+
 @pytest.mark.parametrize("fork_levels", ["0", "3", "16"])
 def test_parallel_bvh_build_is_byte_identical(fork_levels, monkeypatch):
     """the task-parallel build forks the halves of large nodes; whatever the number of forking levels
