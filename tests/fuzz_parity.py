@@ -20,6 +20,9 @@ f32 = np.float32
 WILD = "--wild" in sys.argv
 if WILD:
     sys.argv.remove("--wild")
+RENDERER = "--renderer" in sys.argv  # through the C++ gpuart::Renderer (its own BVH build, camera basis, Sun direction, RandSeed draws)
+if RENDERER:
+    sys.argv.remove("--renderer")
 WILD2 = "--wild2" in sys.argv  # the second class of hostile numbers (gpuart_amd.synth_scenes.random_wild2_case)
 if WILD2:
     sys.argv.remove("--wild2")
@@ -46,17 +49,36 @@ def main():
         acc = np.zeros((H, W, 4), f32)
         for k in range(K):
             O.pt_pass(tree, cam, W, H, P, seeds[k], npaths, acc)
-        gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
-        be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
         res = {}
-        for mode in (0, 2, 3):
-            be.set_mode(mode)
-            be.render_direct(gp); res["direct", mode] = be.read(0)
-            be.pt_reset(); be.pt_plan(K)
-            for k in range(K):
-                be.pt_pass(gp, seeds[k], npaths)
-            res["pt", mode] = be.read(1)
-        be.set_mode(0)
+        if RENDERER:
+            # the whole product: Renderer::SetPrimitives builds, compiles and uploads the tree, SetCamera / the Sun setters compute
+            # what the oracle computes above, RenderPathTracingPass draws the RandSeeds from its own mt19937
+            r = B.Renderer(W, H, cd)
+            r.set_primitives(prims)
+            r.set_sun(case["sun_az"], case["sun_alt"], case["sun_on"])
+            us = case["user_sphere"]
+            r.set_user_sphere(us[:3], us[3], case["us_em"], bool(flags & 2), bool(flags & 4))
+            r.set_max_path_segments(case["max_segments"])
+            for mode in (0, 3):
+                r.backend.set_mode(mode)
+                r.render_direct(); res["direct", mode] = r.read_direct()
+                r.set_seed(5489 + seed)
+                r.restart_path_tracing(npaths, npaths * K)
+                for k in range(K):
+                    r.path_tracing_pass()
+                res["pt", mode] = r.read_radiance(False)
+            r.close()
+        else:
+            gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
+            be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
+            for mode in (0, 2, 3):
+                be.set_mode(mode)
+                be.render_direct(gp); res["direct", mode] = be.read(0)
+                be.pt_reset(); be.pt_plan(K)
+                for k in range(K):
+                    be.pt_pass(gp, seeds[k], npaths)
+                res["pt", mode] = be.read(1)
+            be.set_mode(0)
         ok = True
         for (what, mode), got in res.items():
             exp = exp_direct if what == "direct" else acc

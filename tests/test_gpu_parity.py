@@ -772,6 +772,19 @@ def test_random_scenes_soak(wild):
     assert "60 scenes, 0 with differences" in r.stdout
 
 
+@pytest.mark.parametrize("flavour", ["", "--wild", "--wild2"])
+def test_random_scenes_through_the_renderer_api(flavour):
+    """The same random cases through the C++ gpuart::Renderer — its own BVH build and upload (Renderer::SetPrimitives), camera
+    basis, Sun direction and RandSeed draws instead of the oracle's — in both path-tracing pipelines: the whole product against
+    the oracle, bit for bit (tests/fuzz_parity.py --renderer; 300 plain + 300 wild cases found no difference)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "--renderer"] + ([flavour] if flavour else []) + ["0", "40"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0 and "40 scenes, 0 with differences" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_checkpoint_resume_is_bit_identical(B, tmp_path):
     """8 passes == 3 passes + SaveCheckpoint + (new Renderer) LoadCheckpoint + 5 passes, including the RNG state."""
     cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
