@@ -56,8 +56,11 @@ L1_PEAK_GACC = 1010.0           # the highest vector-L1 (TCP) cache-access rate 
 STEP_PEAK_GVISITS = 227.0       # 64 lanes x 3.55e9 wave-steps/s: the rate at which tools/ubench (k_step) performs the product's traversal step — fetch one
                                 # 64-byte record per lane (every lane its own, L1-resident) + the two aabb_entry tests on it — at k_trace's 6 waves per SIMD
                                 # (8 waves: 3.73e9; fetch alone 4.05e9, tests alone 4.87e9: the hardware overlaps them to 1.14 x the slower one)
-VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling";
-                                # measured on the box: profiles/r02/ubench.txt)
+VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling")
+VALU_MEASURED_GINSTR = 1058.0   # the highest issue rate tools/ubench reaches on the box: independent 4-byte v_add_f32, 128 between two branches, 8 waves per
+                                # SIMD = 2.32 cycles (6 waves: 2.44; 8-byte v_fma_f32: 2.54-2.72; profiles/r02/ubench.txt)
+VALU_SAME_MIX_GINSTR = 846.0    # the product's own box test on registers (87 VALU + 17 SALU per test: selects, dependent chains) at k_trace's 6 waves per SIMD:
+                                # 2.90 cycles per VALU instruction
 
 # The reference's own GLSL on Mesa llvmpipe, measured in the BUILD CONTAINER (8 vCPU; tests/golden/time_llvmpipe.py, output in
 # profiles/r02/llvmpipe_reference_glsl_container.txt). /root/reference cannot travel to the GPU box, so this is a recorded figure,
@@ -356,7 +359,9 @@ def main():
                           "more per access than the calibrating pattern",
             "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s",
                            "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step against 1024 SIMDs x 2.4 GHz / 2 cycles per "
-                                         "wave64 VALU instruction"},
+                                         "wave64 VALU instruction (`peak`); `peak_measured` = the highest rate any tools/ubench loop reaches on the box "
+                                         "(2.32 cycles), `peak_same_instruction_mix` = the product's own box test running on registers at 6 waves per SIMD "
+                                         "(2.90 cycles per VALU instruction)"},
             "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G node visits/s (lane level)",
                             "achieved": round(exe[1] / elapsed / 1e9, 2), "frac": round(exe[1] / elapsed / 1e9 / STEP_PEAK_GVISITS, 4),
                             "definition": "node visits the fast mode executes (device counters, mode-4 replay of the same passes) / wall time, against "
@@ -386,6 +391,10 @@ def main():
             vi["instr_per_pass"] = valu
             vi["achieved"] = round(valu / (ms_step * 1e-3) / 1e9, 2)
             vi["frac"] = round(vi["achieved"] / VALU_PEAK_GINSTR, 4)
+            vi["peak_measured"] = VALU_MEASURED_GINSTR
+            vi["frac_of_measured_peak"] = round(vi["achieved"] / VALU_MEASURED_GINSTR, 4)
+            vi["peak_same_instruction_mix"] = VALU_SAME_MIX_GINSTR
+            vi["frac_of_same_mix_peak"] = round(vi["achieved"] / VALU_SAME_MIX_GINSTR, 4)
             if v.get("SQ_ACTIVE_INST_VALU"):
                 vi["lane_util"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
             pk = prof["valu"][1]
