@@ -27,7 +27,7 @@ for f in ["bench", "bench_cfg2", "bench_cluster", "bench_tree", "bench_4k", "ben
     d = json.loads(open("$OUT/%s.json" % f).read().strip().split("\n")[-1])
     r = d["roofline"]
     print("%-14s %8.1f Mrays/s (executed %8.1f)  %.4f ms/step  single %s  L1 frac %s  valu frac %s  lane_util %s  traffic_frac %s  cpu %s" % (
-        f, d["value"], d["mrays_executed_per_s"], d["ms_per_step"], d["ms_per_frame_single"], r.get("frac"), r["valu_issue"].get("frac"),
+        f, d["value"], d["mrays_executed_per_s"], d["ms_per_step"], d["ms_per_frame_single"], r["l1_accesses"].get("frac"), r["valu_issue"].get("frac"),
         r["valu_issue"].get("lane_util"), r["hbm"].get("traffic_frac"), (d.get("cpu_baseline") or {}).get("value")))
 PY
 cat $OUT/trace_vs_events.txt $OUT/tile_scaling_one_gpu.txt $OUT/bvh_build.txt | tail -30
