@@ -497,7 +497,10 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
                         const float d2 = dot3(dts, dts);  // dist*dist: NIR folds sqrt(a)*sqrt(a) to |a|
                         em_term = f3(l.x / d2, l.y / d2, l.z / d2);
                     }
-                    if (P.sunEnabled == 1) { stage = DL_SUN; start_query(h.p, sun); }
+                    // The reference issues the Sun-shadow query unconditionally (direct_lighting.glsl:170-180); where dot(sun, n) <= 0 its
+                    // Lambert term is vec3(0) whatever the query says (:95-99) and `out += vec3(0)` changes nothing, so this fast
+                    // kernel skips it (k_direct, modes 1 / 2, performs every reference query)
+                    if (P.sunEnabled == 1 && dot3(sun, h.n) > 0) { stage = DL_SUN; start_query(h.p, sun); }
                     else if (P.userSphereFlags & 1u) { stage = DL_EM; start_query(h.p, em_dir); }
                     else { acc = acc + ambient; finished = true; }
                 } else {
