@@ -119,6 +119,7 @@ struct gpuart_hip_ctx {
     uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
+    bool chunk_from_env = false;  ///< GPUART_HIP_CHUNK was given: no per-launch choice of the chunk size
     uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box (converter.h): box tests take the comparison form
     uint32_t max_depth = 0;
     float4 *d_direct = nullptr, *d_accum = nullptr;
@@ -404,6 +405,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->shade_waves = c->num_cus * env_u32("GPUART_HIP_SHADE_WAVES_PER_CU", 24, 1, 64);
     c->run_waves = c->num_cus * env_u32("GPUART_HIP_RUN_WAVES_PER_CU", 4 * GD_RUN_WAVES, 1, 32);
     c->tune.chunk = env_u32("GPUART_HIP_CHUNK", 128, 16, 4096);
+    c->chunk_from_env = getenv("GPUART_HIP_CHUNK") != nullptr;
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
     c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
@@ -552,10 +554,15 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
         if (!c->d_cursor) HIP_TRY(hipMalloc(&c->d_cursor, 64));
         HIP_TRY(hipMemsetAsync(c->d_cursor, 0, sizeof(uint32_t), c->stream));
         const dim3 pgrid(c->direct_waves);  // alone on the GPU: 16 waves per CU measured best
+        // The frame is one launch: its tail is the last chunk a wave takes from the cursor (128 pixels are two rounds of two
+        // dependent queries). Small frames take 64-pixel chunks — 1080p 0.92 -> 0.75 ms per frame; 4K stays at 128 (1.74 against
+        // 1.85): fewer cursor atomics, longer coherent runs (gpurun_out/direct_chunk.txt; 32 and 16 are far worse: 1.0 / 1.7 ms)
+        TraceTuning dtune = c->tune;
+        if (!c->chunk_from_env && c->n_slots / ((size_t)c->direct_waves * 8) < 128) dtune.chunk = 64;
         const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;
-        if (c->exact_boxes) k_direct_persistent<GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
-        else if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
-        else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, c->tune);
+        if (c->exact_boxes) k_direct_persistent<GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        else if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
     }
     HIP_TRY(hipGetLastError());
     return end_timed(c, t);

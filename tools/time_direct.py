@@ -10,7 +10,8 @@ from gpuart_amd import synth_scenes as S  # noqa: E402
 
 cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
 prims = B.make_prims(S.scene_d())
-for W, H in ((1920, 1080), (3840, 2160)):
+frames = [tuple(int(v) for v in a.lower().split('x')) for a in sys.argv[1:]] or [(1920, 1080), (3840, 2160)]
+for W, H in frames:
     r = B.Renderer(W, H, cam)
     r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
     r.set_primitives(prims)
