@@ -678,6 +678,8 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     const int npaths = c->pend_npaths;
     Scene sc = scene_of(c);
     TimedLaunch t;
+    // a lane's path buffers hold max_batch passes (realloc_tile): a longer run would write past them
+    if (!count || count > c->max_batch) return fail(GPUART_HIP_ERR_DEVICE, "internal: a pipeline run longer than its lane's buffers");
     PassLane &l = c->lanes[c->next_lane];
     c->next_lane = (c->next_lane + 1) % c->lanes_in_use;
     l.pb.batch = (uint32_t)count;
