@@ -20,6 +20,9 @@ f32 = np.float32
 WILD = "--wild" in sys.argv
 if WILD:
     sys.argv.remove("--wild")
+SHARES = "--shares" in sys.argv  # the frame rendered as the shares of 2-5 ranks (interleaved row bands, gpuart_hip_set_share) and re-assembled
+if SHARES:
+    sys.argv.remove("--shares")
 RENDERER = "--renderer" in sys.argv  # through the C++ gpuart::Renderer (its own BVH build, camera basis, Sun direction, RandSeed draws)
 if RENDERER:
     sys.argv.remove("--renderer")
@@ -68,6 +71,28 @@ def main():
                     r.path_tracing_pass()
                 res["pt", mode] = r.read_radiance(False)
             r.close()
+        elif SHARES:
+            # what N ranks do, one after the other on this GPU: every rank renders its share of the FIXED frame (bands of
+            # `band` rows dealt round-robin), the shares are scattered into the frame as the gather does on the root
+            gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
+            rs2 = np.random.RandomState(777 + seed)
+            nranks, band = int(rs2.choice([2, 3, 5])), int(rs2.choice([1, 3, 8, 16]))
+            be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
+            for mode in (0, 3):
+                be.set_mode(mode)
+                full_d, full_p = np.zeros((H, W, 4), f32), np.zeros((H, W, 4), f32)
+                for rank in range(nranks):
+                    g = B.share_of_rank(W, H, rank, nranks, band)
+                    if g.th == 0:
+                        continue  # more ranks than bands: nothing to render
+                    be.set_share(g)
+                    be.render_direct(gp); B.scatter_rows_host(g, be.read(0), full_d)
+                    be.pt_reset(); be.pt_plan(K)
+                    for k in range(K):
+                        be.pt_pass(gp, seeds[k], npaths)
+                    B.scatter_rows_host(g, be.read(1), full_p)
+                res["direct", mode], res["pt", mode] = full_d, full_p
+            be.set_mode(0)
         else:
             gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
             be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
