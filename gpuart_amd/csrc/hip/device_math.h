@@ -103,7 +103,7 @@ GD_FN float log2_lp(float x) {
 GD_FN float exp2_lp(float x) {
     const float P0 = 1.0f, P1 = 0.693153073200168932794f, P2 = 0.240153617044375388211f,
                 P3 = 0.0558263180532956664775f, P4 = 0.00898934009049466391101f, P5 = 0.00187757667519147912699f;
-    if (x > 129.0f) x = 129.0f;
+    if (x > 128.0f) x = 128.0f;  // gallivm clamps the argument to [-126.99999, 128]: 2^128 is +inf ((128 + 127) << 23)
     if (x < -126.99999f) x = -126.99999f;
     float ip = floorf(x);
     float fp = x - ip;
@@ -114,6 +114,13 @@ GD_FN float exp2_lp(float x) {
     float p = fmaf(odd, fp, even);
     return e * p;
 }
-GD_FN float pow_lp(float x, float y) { return exp2_lp(log2_lp(x) * y); }
+/// Special bases as llvmpipe answers them (probed; tests/golden/sky_wild.npz): NaN -> 0, a negative base (not zero; -inf too) ->
+/// NaN, +inf and every base whose power overflows -> +inf, +-0 and denormals -> 0 (the last three fall out of the polynomials).
+GD_FN float pow_lp(float x, float y) {
+    const uint32_t b = __float_as_uint(x);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0.0f;
+    if ((b >> 31) && (b & 0x7f800000u)) return __uint_as_float(0x7fc00000u);
+    return exp2_lp(log2_lp(x) * y);
+}
 
 }  // namespace gd

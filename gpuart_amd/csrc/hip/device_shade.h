@@ -39,9 +39,14 @@ GD_FN void camera_ray(const Frame &f, uint32_t x, uint32_t y, F3 &rstart, F3 &rd
 }
 
 // ---- reference shaders/common.glsl:40-46 -----------------------------------------------------
+// As Mesa compiles it: all(lessThan(a, b)) becomes !any(a >= b) (NIR pushes the negation into the comparisons), so a NaN
+// component counts as "small"; the z component of normalize(vec3(v.y, -v.x, 0)) is the constant 0, not 0 * rsq
+// (tests/golden/hemisphere_wild.npz).
 GD_FN F3 get_orthogonal(F3 v) {
-    if (fabsf(v.x) < 1.0e-6f && fabsf(v.y) < 1.0e-6f) return f3(1, 0, 0);
-    return normalize3(f3(v.y, -v.x, 0.0f));
+    if (!(fabsf(v.x) >= 1.0e-6f || fabsf(v.y) >= 1.0e-6f)) return f3(1, 0, 0);
+    const F3 w = f3(v.y, -v.x, 0.0f);
+    const float inv = 1.0f / sqrtf(dot3(w, w));
+    return f3(v.y * inv, -v.x * inv, 0.0f);
 }
 
 // ---- reference shaders/common.glsl:49-66 -----------------------------------------------------
@@ -54,8 +59,9 @@ GD_FN F3 random_hemisphere_direction(F3 v, F3 ri) {
     sincos_lp(a, s, c);
     float x = c * sr2, y = s * sr2, z = sqrtf(r2);
     F3 t = get_orthogonal(v);
-    F3 ct = cross3(v, t);
-    return f3((t.x * x + ct.x * y) + v.x * z, (t.y * x + ct.y * y) + v.y * z, (t.z * x + ct.z * y) + v.z * z);
+    // tangent.z is the constant 0 in both branches of GetOrthogonal: Mesa folds its products away (0 * NaN and 0 * inf included)
+    F3 ct = f3(-(v.z * t.y), v.z * t.x, v.x * t.y - v.y * t.x);
+    return f3((t.x * x + ct.x * y) + v.x * z, (t.y * x + ct.y * y) + v.y * z, ct.z * y + v.z * z);
 }
 
 // ---- reference shaders/common.glsl:69-76 (GLSL mat3 is column-major) --------------------------
@@ -89,7 +95,13 @@ GD_FN F3 random_direction_inside_cone(F3 v, F3 normal, float halfAngle, F3 ri) {
 GD_FN F3 sky_color(F3 dir, const float sda[4]) {
     F3 nd = normalize3(dir);
     F3 hp = f3(nd.x, nd.y, 0.0f);  // cross(cross((0,0,1), nd), (0,0,1))
-    float weight = (dir.z >= 0) ? dot3(nd, normalize3(hp)) : 1.0f;
+    // hp.z is the constant 0: Mesa folds 0 * rsq(...) and nd.z * 0 away (also where rsq is inf: |hp| underflows for a direction
+    // close to the zenith), so the z term never makes a NaN; what is left of dot() is its (y + x) part (tests/golden/sky_wild.npz)
+    float weight = 1.0f;
+    if (dir.z >= 0) {
+        const float inv = 1.0f / sqrtf(dot3(hp, hp));
+        weight = nd.y * (hp.y * inv) + nd.x * (hp.x * inv);
+    }
     float sw = 1.0f - sda[3] / (3.1415926f / 2);
     F3 cz = f3(mixf(0.2f, 0.0f, sw), mixf(0.6f, 0.2f, sw), mixf(1.0f, 0.5f, sw));
     F3 ch = f3(1.0f, mixf(1.0f, 0.647f, sw), mixf(1.0f, 0.367f, sw));

@@ -34,9 +34,12 @@ float random4(V4 v) {
 
 // ---- common.glsl -------------------------------------------------------------------------
 // common.glsl:40-46
+// As Mesa compiles it: all(lessThan(a, b)) becomes !any(a >= b) (NIR pushes the negation into the comparison), so a NaN
+// component counts as "small"; the z component of normalize(vec3(v.y, -v.x, 0)) is the constant 0, not 0 * rsq.
 V3 GetOrthogonal(V3 v) {
-    if (fabsf(v.x) < 1.0e-6f && fabsf(v.y) < 1.0e-6f) return V3{1, 0, 0};
-    return normalize3(V3{v.y, -v.x, 0.0f});
+    if (!(fabsf(v.x) >= 1.0e-6f || fabsf(v.y) >= 1.0e-6f)) return V3{1, 0, 0};
+    const float inv = rsq(dot3(V3{v.y, -v.x, 0.0f}, V3{v.y, -v.x, 0.0f}));
+    return V3{v.y * inv, -v.x * inv, 0.0f};
 }
 
 // common.glsl:49-66
@@ -49,8 +52,9 @@ V3 GetRandomHemisphereDirection(V3 v, V3 ri) {
     sincos_lp(_2pr1, &s, &c);
     float x = c * sr2, y = s * sr2, z = sqrtf(r2);
     V3 t = GetOrthogonal(v);
-    V3 ct = cross3(v, t);
-    return V3{(t.x * x + ct.x * y) + v.x * z, (t.y * x + ct.y * y) + v.y * z, (t.z * x + ct.z * y) + v.z * z};
+    // tangent.z is the constant 0 in both branches of GetOrthogonal: Mesa folds its products away (0 * NaN and 0 * inf included)
+    V3 ct{-(v.z * t.y), v.z * t.x, v.x * t.y - v.y * t.x};
+    return V3{(t.x * x + ct.x * y) + v.x * z, (t.y * x + ct.y * y) + v.y * z, ct.z * y + v.z * z};
 }
 
 // common.glsl:69-76 — GLSL mat3 constructor is column-major; M*v = (col0*v.x + col1*v.y) + col2*v.z.
@@ -332,9 +336,12 @@ V3 GetSkyColor(V3 dir, const float sda[4]) {
     // cross(cross((0,0,1), nd), (0,0,1)) = (nd.x, nd.y, 0)
     V3 hp{nd.x, nd.y, 0.0f};
     float weight;
-    if (dir.z >= 0)
-        weight = dot3(nd, normalize3(hp));
-    else
+    if (dir.z >= 0) {
+        // hp.z is the constant 0: Mesa folds 0 * rsq(...) and nd.z * 0 away (also where rsq is inf: |hp| underflows for a direction
+        // close to the zenith), so the z term never makes a NaN; what is left of dot() is its (y + x) part
+        const float inv = rsq(dot3(hp, hp));
+        weight = nd.y * (hp.y * inv) + nd.x * (hp.x * inv);
+    } else
         weight = 1;
     float sunWeight = 1.0f - sda[3] / (3.1415926f / 2);
     const V3 ZH{0.2f, 0.6f, 1}, ZL{0, 0.2f, 0.5f}, HH{1, 1, 1}, HL{1, 0.647f, 0.367f};

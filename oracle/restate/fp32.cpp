@@ -82,7 +82,7 @@ static float log2_lp(float x) {
 static float exp2_lp(float x) {
     static const float P[] = {1.000000000000000000000f, 0.693153073200168932794f, 0.240153617044375388211f,
                               0.0558263180532956664775f, 0.00898934009049466391101f, 0.00187757667519147912699f};
-    if (x > 129.0f) x = 129.0f;
+    if (x > 128.0f) x = 128.0f;  // gallivm clamps the argument to [-126.99999, 128]: 2^128 is +inf ((128 + 127) << 23), what pow() of an infinite base gives
     if (x < -126.99999f) x = -126.99999f;
     float ip = floorf(x);
     float fp = x - ip;
@@ -91,6 +91,14 @@ static float exp2_lp(float x) {
     return e * p;
 }
 
-float pow_lp(float x, float y) { return exp2_lp(log2_lp(x) * y); }
+// Special bases as llvmpipe answers them (probed: tests/golden/make_golden.py shade_wild and the table in oracle/README.md):
+// NaN -> 0, a negative base (not zero; -inf too) -> NaN, +inf and every base whose power overflows -> +inf,
+// +-0 and denormals -> 0. The last three fall out of the polynomials and the clamp; the first two are gallivm's edge handling.
+float pow_lp(float x, float y) {
+    const uint32_t b = f2u(x);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0.0f;              // NaN of either sign (0 * inf is the negative default NaN on x86)
+    if ((b >> 31) && (b & 0x7f800000u)) return u2f(0x7fc00000u);  // (negative denormals are flushed to -0 first: log2 = -inf, result 0)
+    return exp2_lp(log2_lp(x) * y);
+}
 
 }  // namespace orc

@@ -200,6 +200,104 @@ def gen_cone(gl):
     save("cone", rs=rs, rd=rd, c1=c1, c2=c2, r1=r1, r2=r2, quads=q, o0=o[0], o1=o[1])
 
 
+HOSTILE = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, -1e-30, -0.0, 0.0, 1e19, -1e19, 1e-4, -1e-4, 1e-8, 1e-10, 3.4028234e38,
+                    -3.4028234e38, 1.17549435e-38, 1e-39, 1e-45, -1e-45, 1e10, -1e10, 0.5, -0.3, -1.0, 1.0], np.float32)
+CUT = "if (pos < 1.0e-4) pos = -1;"  # CheckBVHPrimitiveIntersection's visibility cut (bvh_intersection.glsl:170), as in the cone probe
+
+
+def inject(rng, arrays, frac=0.35):
+    """Replaces 1-3 random components of `frac` of the rows (of the arrays taken together) by hostile values or by their negation."""
+    n = len(arrays[0])
+    widths = [a.shape[1] for a in arrays]
+    for i in np.nonzero(rng.uniform(size=n) < frac)[0]:
+        for _ in range(int(rng.randint(1, 4))):
+            k = int(rng.randint(len(arrays)))
+            c = int(rng.randint(widths[k]))
+            arrays[k][i, c] = -arrays[k][i, c] if rng.uniform() < 0.2 else HOSTILE[int(rng.randint(len(HOSTILE)))]
+
+
+def gen_intersect_wild(gl):
+    """The four intersectors on hostile numbers (NaN, +-inf, +-1e30, denormals, negative radii, the reference's own magic numbers)
+    in the primitive AND in the ray: what wild scenes feed them. Outputs as CheckBVHPrimitiveIntersection leaves them."""
+    n = 4096
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    rng = np.random.RandomState(9001)
+    c = rng.uniform(-1, 1, (n, 3)); r = rng.uniform(0.05, 1.0, (n, 1))
+    rs, rd = rays_towards(rng, n, c, r * 0.8)
+    rs, rd, sph = f(rs), f(rd), f(np.concatenate([c, r], 1))
+    inject(rng, [rs, rd, sph])
+    o = glref.run_probe(gl, "float pos; vec3 p, n; SphereIntersection(i0.xyz, i1.xyz, i2.xyz, i2.w, pos, p, n);" + CUT + HIT_OUT,
+                        GEOM, [pad4(rs), pad4(rd), sph], 2, decls=D_SPHERE)
+    save("sphere_wild", rs=rs, rd=rd, sph=sph, o0=o[0], o1=o[1])
+
+    rng = np.random.RandomState(9002)
+    c = rng.uniform(-1, 1, (n, 3)); r = rng.uniform(0.05, 1.5, (n, 1)); dn = unit(rng.normal(size=(n, 3)))
+    rs, rd = rays_towards(rng, n, c, r * 0.9)
+    rs, rd, cr, dn = f(rs), f(rd), f(np.concatenate([c, r], 1)), f(dn)
+    inject(rng, [rs, rd, cr, dn])
+    o = glref.run_probe(gl, "float pos; vec3 p, n; DiscIntersection(i0.xyz, i1.xyz, i2.xyz, i2.w, i3.xyz, pos, p, n);" + CUT + HIT_OUT,
+                        GEOM, [pad4(rs), pad4(rd), cr, pad4(dn)], 2, decls=D_DISC)
+    save("disc_wild", rs=rs, rd=rd, cr=cr, dn=dn, o0=o[0], o1=o[1])
+
+    rng = np.random.RandomState(9003)
+    v0 = rng.uniform(-1, 1, (n, 3))
+    v1 = v0 + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1, (n, 1)); v2 = v0 + rng.normal(size=(n, 3)) * rng.uniform(0.01, 1, (n, 1))
+    bary = rng.dirichlet([1, 1, 1], n)
+    aim = bary[:, :1] * v0 + bary[:, 1:2] * v1 + bary[:, 2:] * v2
+    rs = rng.uniform(-3, 3, (n, 3)); rd = (aim - rs) * rng.uniform(0.05, 2.0, (n, 1))
+    rs, rd, v0, v1, v2 = f(rs), f(rd), f(v0), f(v1), f(v2)
+    inject(rng, [rs, rd, v0, v1, v2])
+    o = glref.run_probe(gl, "float pos; vec3 p, n; vec2 uv; TriangleIntersection(i0.xyz, i1.xyz, i2.xyz, i3.xyz, i4.xyz, pos, p, n, uv);"
+                        + CUT + HIT_OUT, GEOM, [pad4(rs), pad4(rd), pad4(v0), pad4(v1), pad4(v2)], 2, decls=D_TRI)
+    save("triangle_wild", rs=rs, rd=rd, v0=v0, v1=v1, v2=v2, o0=o[0], o1=o[1])
+
+    rng = np.random.RandomState(9004)
+    c1 = f(rng.uniform(-1, 1, (n, 3))); ax = unit(rng.normal(size=(n, 3))); ln = rng.uniform(0.1, 1.5, (n, 1))
+    c2 = f(c1 + ax * ln); r1 = f(rng.uniform(0.02, 0.5, (n, 1))); r2 = f(rng.uniform(0.02, 0.5, (n, 1)))
+    mid = (c1 + c2) / 2 + ax * ln * rng.uniform(-0.6, 0.6, (n, 1))
+    rs, rd = rays_towards(rng, n, mid, np.maximum(r1, r2) * 0.9)
+    rs, rd = f(rs), f(rd)
+    half = n // 2
+    inject(rng, [c1[:half], c2[:half], r1[:half], r2[:half]], 0.5)       # hostile cone parameters through Cone::Cone's double arithmetic
+    q = cone_quads(c1, c2, r1[:, 0], r2[:, 0])
+    inject(rng, [rs, rd])
+    inject(rng, [q[half:]], 0.5)                                         # hostile values straight in the payload the shader reads
+    o = glref.run_probe(gl, "float pos; vec3 p, n; ConeIntersection(i0.xyz, i1.xyz, i2, i3, i4, i5.x, i5.y, i5.z, pos, p, n);" + CUT + HIT_OUT,
+                        GEOM, [pad4(rs), pad4(rd), q[:, 0:4], q[:, 4:8], q[:, 8:12], q[:, 12:16]], 2, decls=D_CONE)
+    save("cone_wild", rs=rs, rd=rd, c1=c1, c2=c2, r1=r1, r2=r2, quads=q, o0=o[0], o1=o[1])
+
+
+def gen_shade_wild(gl):
+    """random(), the two direction samplers and the sky on hostile inputs (what a path that bounced off a wild primitive carries:
+    NaN / infinite hit points and normals, huge seeds)."""
+    n = 4096
+    rng = np.random.RandomState(9101)
+    x = rng.uniform(-4, 4, (n, 4)).astype(np.float32)
+    inject(rng, [x], 0.6)
+    o, = glref.run_probe(gl, "O0 = vec4(random(i0.x), random(i0.xy), random(i0.xyz), random(i0));", ["noise.glsl"], [x], 1, decls=D_RANDOM)
+    save("hash_wild", x=x, out=o)
+    v = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    ri = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    inject(rng, [v, ri], 0.5)
+    o, = glref.run_probe(gl, "O0 = vec4(GetRandomHemisphereDirection(i0.xyz, i1.xyz), 0);", ["common.glsl", "noise.glsl"],
+                         [pad4(v), pad4(ri)], 1, decls=D_HEMI)
+    save("hemisphere_wild", v=v, ri=ri, out=o[:, :3].copy())
+    nrm = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    vv = (unit(rng.normal(size=(n, 3)) + 1.5 * nrm) * rng.uniform(0.2, 3, (n, 1))).astype(np.float32)
+    ri2 = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    inject(rng, [vv, nrm, ri2], 0.5)
+    o, = glref.run_probe(gl, "O0 = vec4(GetRandomDirectionInsideCone(i0.xyz, i1.xyz, 10 * 3.14159/180, i2.xyz), 0);",
+                         ["common.glsl", "noise.glsl"], [pad4(vv), pad4(nrm), pad4(ri2)], 1, decls=D_ICONE)
+    save("inside_cone_wild", v=vv, normal=nrm, ri=ri2, out=o[:, :3].copy())
+    d = (unit(rng.normal(size=(n, 3))) * rng.uniform(0.1, 3, (n, 1))).astype(np.float32)
+    inject(rng, [d], 0.5)
+    alt = np.float32(0.7)
+    sun = O.sun_direction(S.SUN_AZIMUTH, alt)
+    sda = [float(sun[0]), float(sun[1]), float(sun[2]), float(alt)]
+    o, = glref.run_probe(gl, "O0 = vec4(GetSkyColor(i0.xyz, i1), 0);", ["sky.glsl"], [pad4(d), np.tile(np.array(sda, np.float32), (n, 1))], 1, decls=D_SKY)
+    save("sky_wild", dir=d, sun_dir_alt=np.array(sda, np.float32), out=o[:, :3].copy())
+
+
 def gen_aabb(gl):
     rng = np.random.RandomState(18)
     n = 4096
@@ -579,7 +677,7 @@ def gen_cluster_tree(gl):
 
 
 SECTIONS = dict(scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

@@ -113,6 +113,45 @@ def test_intersectors(be):
     assert_bits(np.concatenate(o, 1), np.concatenate([g["o0"], g["o1"]], 1), "cone")
 
 
+def test_intersectors_on_hostile_numbers(be):
+    """The device intersectors (through the uploader's re-layout of the canonical payload) with NaN / +-inf / +-1e30 / denormals /
+    negative radii / the reference's magic numbers in the primitive and in the ray, against the reference's GLSL on llvmpipe
+    (tests/golden/*_wild.npz, make_golden.py intersect_wild; the probe applies CheckBVHPrimitiveIntersection's visibility cut)."""
+    def check(name, ptype, g, quads):
+        o = be.test_intersect(ptype, pad4(g["rs"]), pad4(g["rd"]), quads)
+        got, exp = np.concatenate(o, 1), np.concatenate([g["o0"], g["o1"]], 1)
+        same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+        bad = ~same.all(1)
+        assert not bad.any(), "%s: %d of %d rows differ; first: row %d got %s expected %s" % (name, int(bad.sum()), len(bad),
+                                                                                             int(np.nonzero(bad)[0][0]), got[bad][0], exp[bad][0])
+    g = golden("sphere_wild"); check("sphere", S.SPHERE, g, _payload(len(g["rs"]), g["sph"]))
+    g = golden("disc_wild"); check("disc", S.DISC, g, _payload(len(g["rs"]), g["cr"], g["dn"]))
+    g = golden("triangle_wild"); check("triangle", S.TRIANGLE, g, _payload(len(g["rs"]), g["v0"], g["v1"], g["v2"]))
+    g = golden("cone_wild"); check("cone", S.CONE, g, g["quads"])
+
+
+def test_shading_functions_on_hostile_numbers(be):
+    """random(), the two direction samplers and the sky on NaN / infinite / huge / denormal inputs (what a path carries after
+    bouncing off a wild primitive), against the reference's GLSL on llvmpipe (tests/golden/*_wild.npz, make_golden.py shade_wild):
+    Mesa's NaN-unsafe foldings (all(lessThan()) as !any(>=), constant-0 components folded out of products) and gallivm's pow() on
+    NaN / inf / overflowing bases are part of what the reference computes."""
+    def nanbits(got, exp, what):
+        got, exp = np.asarray(got, np.float32), np.asarray(exp, np.float32)
+        same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+        bad = ~same.reshape(len(got), -1).all(1)
+        assert not bad.any(), "%s: %d of %d rows differ; first: row %d got %s expected %s" % (what, int(bad.sum()), len(bad),
+                                                                                             int(np.nonzero(bad)[0][0]), got[bad][0], exp[bad][0])
+    g = golden("hash_wild")
+    nanbits(be.test_random(g["x"]), g["out"], "random")
+    g = golden("hemisphere_wild")
+    nanbits(be.test_hemisphere(pad4(g["v"]), pad4(g["ri"]))[:, :3], g["out"], "hemisphere sampler")
+    g = golden("inside_cone_wild")
+    ha = np.float32(10) * np.float32(3.14159) / np.float32(180)
+    nanbits(be.test_inside_cone(pad4(g["v"]), pad4(g["normal"]), pad4(g["ri"]), float(ha))[:, :3], g["out"], "cone sampler")
+    g = golden("sky_wild")
+    nanbits(be.test_sky(pad4(g["dir"]), g["sun_dir_alt"])[:, :3], g["out"], "sky")
+
+
 def test_aabb(be):
     g = golden("aabb")
     assert_bits(be.test_aabb(pad4(g["rs"]), pad4(g["rd"]), pad4(g["bmin"]), pad4(g["bmax"]))[:, :2], g["out"], "AABB")

@@ -77,6 +77,59 @@ def test_cone():
     assert_bits(_hit([o0, o1]), _hit([g["o0"], g["o1"]]), "ConeIntersection")
 
 
+def _cut(o0, o1):
+    """CheckBVHPrimitiveIntersection's visibility cut + the probe's output shape (pos > 0: pos, P, N; else pos alone)."""
+    o0, o1 = o0.copy(), o1.copy()
+    o0[o0[:, 0] < 1e-4, 0] = -1
+    keep = o0[:, 0] > 0
+    o0[~keep, 1:] = 0
+    o1[~keep] = 0
+    return np.concatenate([o0, o1], 1)
+
+
+def _bits_or_nan(got, exp, what):
+    same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+    bad = ~same.all(1)
+    assert not bad.any(), "%s: %d of %d rows differ; first: row %d got %s expected %s" % (what, int(bad.sum()), len(bad), int(np.nonzero(bad)[0][0]),
+                                                                                         got[bad][0], exp[bad][0])
+
+
+def test_shading_functions_on_hostile_numbers():
+    """random(), GetRandomHemisphereDirection, GetRandomDirectionInsideCone and GetSkyColor on NaN / infinite / huge / denormal
+    inputs (what a path carries after bouncing off a wild primitive), against the reference's GLSL on llvmpipe."""
+    def nanbits(got, exp, what):
+        got, exp = np.asarray(got, np.float32), np.asarray(exp, np.float32)
+        same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+        bad = ~same.reshape(len(got), -1).all(1)
+        assert not bad.any(), "%s: %d of %d rows differ; first: row %d got %s expected %s" % (what, int(bad.sum()), len(bad),
+                                                                                             int(np.nonzero(bad)[0][0]), got[bad][0], exp[bad][0])
+    g = golden("hash_wild")
+    nanbits(O.random(g["x"]), g["out"], "random")
+    g = golden("hemisphere_wild")
+    nanbits(O.hemisphere(pad4(g["v"]), pad4(g["ri"]))[:, :3], g["out"], "GetRandomHemisphereDirection")
+    g = golden("inside_cone_wild")
+    ha = np.float32(10) * np.float32(3.14159) / np.float32(180)  # the probe's constant, folded in float as GLSL folds it
+    nanbits(O.inside_cone(pad4(g["v"]), pad4(g["normal"]), pad4(g["ri"]), ha)[:, :3], g["out"], "GetRandomDirectionInsideCone")
+    g = golden("sky_wild")
+    nanbits(O.sky(pad4(g["dir"]), g["sun_dir_alt"])[:, :3], g["out"], "GetSkyColor")
+
+
+def test_intersectors_on_hostile_numbers():
+    """The four intersectors with NaN / +-inf / +-1e30 / denormals / negative radii / the reference's magic numbers in the
+    primitive and in the ray, against the reference's GLSL on llvmpipe (tests/golden/make_golden.py intersect_wild)."""
+    g = golden("sphere_wild")
+    assert 0.05 < (g["o0"][:, 0] > 0).mean()
+    _bits_or_nan(_cut(*O.sphere(pad4(g["rs"]), pad4(g["rd"]), g["sph"])), np.concatenate([g["o0"], g["o1"]], 1), "SphereIntersection")
+    g = golden("disc_wild")
+    _bits_or_nan(_cut(*O.disc(pad4(g["rs"]), pad4(g["rd"]), g["cr"], pad4(g["dn"]))), np.concatenate([g["o0"], g["o1"]], 1), "DiscIntersection")
+    g = golden("triangle_wild")
+    _bits_or_nan(_cut(*O.triangle(*[pad4(g[k]) for k in ["rs", "rd", "v0", "v1", "v2"]])), np.concatenate([g["o0"], g["o1"]], 1), "TriangleIntersection")
+    g = golden("cone_wild")
+    q = g["quads"]
+    _bits_or_nan(_cut(*O.cone(pad4(g["rs"]), pad4(g["rd"]), q[:, 0:4], q[:, 4:8], q[:, 8:12], q[:, 12:16])), np.concatenate([g["o0"], g["o1"]], 1),
+                 "ConeIntersection")
+
+
 def test_aabb():
     g = golden("aabb")
     assert 0.2 < g["out"][:, 0].mean() < 0.9
