@@ -547,6 +547,30 @@ def gen_traverse(gl):
              rs2=rs2[:, :3].copy(), rd2=rd2[:, :3].copy(), s0=s0, s1=s1)
 
 
+def gen_traverse_wild(gl):
+    """CheckIntersectionInclUserSphere with hostile rays on a regular tree (scene_pc) and with regular + hostile rays on the trees
+    of wild scenes (irregular boxes, degenerate 200-level chains: random_wild_case 42874 and 7; random_wild2_case 5), user sphere
+    of radius 0.25 included. The tree travels in the fixture."""
+    rng = np.random.RandomState(9201)
+    # (the user sphere travels as an input, not as a literal: a literal lets the compiler fold `- 0` and `0.25 * 0.25` into
+    #  SphereIntersection, which the renderer's uniform never allows)
+    body = ("float pos; vec3 p, n; int t; bool ush; CheckIntersectionInclUserSphere(i0.xyz, i1.xyz, BVH, i2, pos, p, n, t, ush);"
+            "if (t >= 0) { O0 = vec4(pos, p); O1 = vec4(n, float(t) + (ush ? 0.5 : 0.0)); } else { O0 = vec4(-1, 0, 0, 0); O1 = vec4(0, 0, 0, -1); }")
+    objs = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "common.glsl", "noise.glsl", "bvh_intersection.glsl", "intersection.glsl"]
+    trees = [("scene_pc", scene_tree("scene_pc")[1]), ("wild_42874", O.build_bvh(S.random_wild_case(42874)["prims"])[0]),
+             ("wild_7", O.build_bvh(S.random_wild_case(7)["prims"])[0]), ("wild2_5", O.build_bvh(S.random_wild2_case(5)["prims"])[0])]
+    for name, tree in trees:
+        n = 4096
+        rs = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32); rs[:, 2] = np.abs(rs[:, 2])
+        aim = rng.uniform(-1.2, 1.2, (n, 3)); aim[:, 2] = np.abs(aim[:, 2])
+        rd = ((aim - rs) * rng.uniform(0.05, 2.0, (n, 1))).astype(np.float32)
+        inject(rng, [rs[n // 2:], rd[n // 2:]], 0.7)   # second half: hostile rays
+        us = np.tile(np.array([-0.4, 0, 0.2, 0.25], np.float32), (n, 1))
+        o0, o1 = glref.run_probe_big(gl, body, objs, [pad4(rs), pad4(rd), us], 2, bvh=tree, decls=D_INCL, chunk=4096)
+        print("traverse_wild %s: %d of %d rays hit" % (name, int((o1[:, 3] >= 0).sum()), n))
+        save("traverse_wild_" + name, tree=tree, rs=rs, rd=rd, o0=o0, o1=o1)
+
+
 def gen_frames(gl):
     seeds = O.randseeds(16)
     for name, (W, H), camsel, segs in [("box", (128, 128), S.DEFAULT_CAMERA, [5, 1, 4, 8]),
@@ -677,7 +701,7 @@ def gen_cluster_tree(gl):
 
 
 SECTIONS = dict(scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

@@ -228,6 +228,21 @@ def test_traversal(be, O, name):
         assert ((a0[:, 0] > 0) == bvh_hit).all()
 
 
+@pytest.mark.parametrize("name", ["scene_pc", "wild_42874", "wild_7", "wild2_5"])
+def test_traversal_with_hostile_rays_and_trees(be, name):
+    """The device traversal (closest hit incl. the user sphere, radius 0.25) with hostile rays on a regular tree and with regular +
+    hostile rays on the trees of wild scenes (irregular boxes -> the exact box test; a 200-level chain -> the spilled stack),
+    against the reference's CheckIntersectionInclUserSphere on llvmpipe (make_golden.py traverse_wild; the tree is in the fixture)."""
+    g = golden("traverse_wild_" + name)
+    be.upload_bvh(g["tree"])
+    o0, o1 = be.test_traverse(pad4(g["rs"]), pad4(g["rd"]), (-0.4, 0.0, 0.2, 0.25))
+    got, exp = np.concatenate([o0, o1], 1), np.concatenate([g["o0"], g["o1"]], 1)
+    same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+    bad = ~same.all(1)
+    assert not bad.any(), "%d of %d rays differ; first: ray %d o %s d %s got %s expected %s" % (
+        int(bad.sum()), len(bad), int(np.nonzero(bad)[0][0]), g["rs"][bad][0], g["rd"][bad][0], got[bad][0], exp[bad][0])
+
+
 def deep_chain_scene(n=40):
     """Spheres at x = 2^k: every split peels one sphere off -> tree depth n-1 > LDS stack depth."""
     return [(S.SPHERE, [float(2.0 ** k), 0.0, 0.0, float(2.0 ** (k - 2))]) for k in range(n)]

@@ -94,6 +94,19 @@ def _bits_or_nan(got, exp, what):
                                                                                          got[bad][0], exp[bad][0])
 
 
+@pytest.mark.parametrize("name", ["scene_pc", "wild_42874", "wild_7", "wild2_5"])
+def test_traversal_with_hostile_rays_and_trees(name):
+    """CheckIntersectionInclUserSphere with hostile rays on a regular tree and with regular + hostile rays on the trees of wild
+    scenes (irregular boxes, a 200-level chain), user sphere of radius 0.25, against the reference's GLSL on llvmpipe."""
+    g = golden("traverse_wild_" + name)
+    o0, o1 = O.traverse(g["tree"], pad4(g["rs"]), pad4(g["rd"]), (-0.4, 0.0, 0.2, 0.25))
+    got, exp = np.concatenate([o0, o1], 1), np.concatenate([g["o0"], g["o1"]], 1)
+    same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+    bad = ~same.all(1)
+    assert not bad.any(), "%d of %d rays differ; first: ray %d o %s d %s got %s expected %s" % (
+        int(bad.sum()), len(bad), int(np.nonzero(bad)[0][0]), g["rs"][bad][0], g["rd"][bad][0], got[bad][0], exp[bad][0])
+
+
 def test_shading_functions_on_hostile_numbers():
     """random(), GetRandomHemisphereDirection, GetRandomDirectionInsideCone and GetSkyColor on NaN / infinite / huge / denormal
     inputs (what a path carries after bouncing off a wild primitive), against the reference's GLSL on llvmpipe."""
