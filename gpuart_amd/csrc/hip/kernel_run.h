@@ -49,6 +49,9 @@
 #ifndef RUN_TAIL_DIV
 #define RUN_TAIL_DIV 2                ///< tail: retire / shade once the finished lanes are 1/RUN_TAIL_DIV of the traversing ones
 #endif
+// Occupancy (gpurun_out/ab_occ.txt): 5 waves per SIMD need <= 96 VGPRs = 9 spilled registers and RUN_RQ 256 (7.5 KB of LDS): 64 passes as
+// one run 1.08 against 1.175 ms per pass, but one pass alone 2.37 against 2.21 and a 1/8 share with 20 passes unchanged; 6 waves (80 VGPRs,
+// 28 spills, 6-entry ring) lose everywhere. The shading code inside the kernel sets the register count; 4 waves it stays.
 #ifndef GD_RUN_WAVES
 #define GD_RUN_WAVES 4              ///< waves per SIMD: 8.5 KB of LDS per wave -> 18 waves per CU; <= 128 VGPRs (shading code inside)
 #endif
@@ -62,7 +65,7 @@ __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-t
 
 namespace {
 
-static_assert((RUN_RQ & (RUN_RQ - 1)) == 0 && RUN_RQ >= 512, "the ready list is a ring indexed modulo RUN_RQ and must hold two entries for each of 256 live paths");
+static_assert((RUN_RQ & (RUN_RQ - 1)) == 0 && RUN_RQ >= 256, "the ready list is a ring indexed modulo RUN_RQ and holds two entries for each of RUN_RQ / 2 live paths (generation stops there)");
 static_assert(RUN_SQ >= 2 * BLOCK, "RETIRE appends up to 64 entries to a shade list of up to 63");
 
 template <bool COUNT, bool REFWORK, int TYPES>
@@ -209,7 +212,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             }
             // ahead of need while the wave holds few live paths (RUN_LIVE_MAX): the sooner a path is born the sooner its chain of
             // up to five segments ends; never beyond 256 live paths (<= 512 entries)
-            if (exhausted || n_live + BLOCK > 256u || !(want_rays || n_live + BLOCK <= (uint32_t)RUN_LIVE_MAX)) break;
+            if (exhausted || n_live + BLOCK > (uint32_t)(RUN_RQ / 2) || !(want_rays || n_live + BLOCK <= (uint32_t)RUN_LIVE_MAX)) break;
             // ---- generate 64 paths: the next 8x8 pixel tile of a pass (path_tracing.glsl:141-175)
             uint32_t base;
             if (first_chunk) {
