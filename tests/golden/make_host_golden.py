@@ -58,6 +58,27 @@ do = np.zeros((256, 36), np.float64)
 for i in range(256):
     L.mref_vec3d_ops(p(da[i].copy()), p(db[i].copy()), C.c_double(ds[i]), p(do[i]))
 
-np.savez_compressed(os.path.join(HERE, "host_math.npz"), sun_in=sun_in, sun_out=sun_out, cam_in=cam_in, cam_out=cam_out,
+# ---- cones: Cone::Cone's constants (double arithmetic) + world box, incl. cylinders, pointed, zero-length, negative and hostile values ----
+nc = 1024
+cc1 = rng.uniform(-2, 2, (nc, 3)).astype(np.float32)
+cc2 = (cc1 + rng.normal(size=(nc, 3)) * rng.uniform(0.01, 2, (nc, 1))).astype(np.float32)
+cr1 = rng.uniform(0.0, 0.6, nc).astype(np.float32)
+cr2 = rng.uniform(0.0, 0.6, nc).astype(np.float32)
+cr2[:128] = cr1[:128]                       # cylinders: CosB = 0
+cr2[128:192] = 0                            # pointed
+cr2[192:224] = cr1[192:224] + np.float32(5e-8)  # |r1 - r2| just below the 1e-7 cut
+cc2[224:240] = cc1[224:240]                 # zero length: AxisLen = 0, the divisions give inf / NaN
+hostile = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, -0.0, -0.3, 1e19, 3.4028234e38, 1e-45], np.float32)
+for i in range(240, 400):
+    arr = [cc1, cc2][int(rng.integers(2))] if rng.uniform() < 0.6 else None
+    v = hostile[int(rng.integers(len(hostile)))]
+    if arr is not None: arr[i, int(rng.integers(3))] = v
+    elif rng.uniform() < 0.5: cr1[i] = v
+    else: cr2[i] = v
+cone_out = np.zeros((nc, 22), np.float32)
+for i in range(nc):
+    L.mref_cone(p(cc1[i].copy()), p(cc2[i].copy()), C.c_float(cr1[i]), C.c_float(cr2[i]), p(cone_out[i]))
+
+np.savez_compressed(os.path.join(HERE, "host_math.npz"), cone_c1=cc1, cone_c2=cc2, cone_r1=cr1, cone_r2=cr2, cone_out=cone_out, sun_in=sun_in, sun_out=sun_out, cam_in=cam_in, cam_out=cam_out,
                     vec3f_a=fa, vec3f_b=fb, vec3f_s=fs, vec3f_out=fo, vec3d_a=da, vec3d_b=db, vec3d_s=ds, vec3d_out=do)
-print("host_math.npz: %d sun directions, %d cameras, %d + %d Vec3 cases" % (len(sun_in), len(cam_in), 512, 256))
+print("host_math.npz: %d sun directions, %d cameras, %d + %d Vec3 cases, %d cones" % (len(sun_in), len(cam_in), 512, 256, nc))

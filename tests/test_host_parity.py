@@ -280,3 +280,23 @@ def test_vec3_operations_equal_reference_math_types():
         ui = np.uint32 if dt == np.float32 else np.uint64
         same = (got.view(ui) == exp.view(ui)) | (np.isnan(got) & np.isnan(exp))
         assert same.all(), "%s: %d of %d values differ from the reference's" % (tag, int((~same).sum()), same.size)
+
+
+def test_cone_constants_equal_reference_vec3_arithmetic():
+    """Cone::Cone's derived constants (src/core.cpp:191-226: axis, length, widthCoeff, cosB, dot(axis, c1), computed in double) and
+    its world box, as the statements give them on the reference's own compiled Vec3f / Vec3d (oracle/mathref/mathref.cpp), for 1 024
+    cones incl. cylinders, pointed and zero-length ones, |r1 - r2| at the 1e-7 cut and hostile values: the payload the oracle and the
+    product store for the cone (StoreDataIntoBVH order, :230-245) equals it bit for bit; so does the node box of a one-cone tree
+    wherever the cone's box holds no NaN (a NaN never enters a node box: the build's min / max comparisons skip it)."""
+    g = _host_math()
+    for i in range(len(g["cone_c1"])):
+        d = (S.CONE, [float(x) for x in g["cone_c1"][i]] + [float(x) for x in g["cone_c2"][i]] + [float(g["cone_r1"][i]), float(g["cone_r2"][i])])
+        exp = g["cone_out"][i]
+        for name, fn in (("oracle", O.build_bvh), ("product", B.compile_bvh)):
+            tree, _ = fn([d])
+            pay = tree[4:8].ravel().astype(np.float32)
+            same = (pay.view(np.uint32) == exp[:16].view(np.uint32)) | (np.isnan(pay) & np.isnan(exp[:16]))
+            assert same.all(), "%s cone %d payload: got %s expected %s" % (name, i, pay, exp[:16])
+            if not np.isnan(exp[16:]).any():
+                box = np.concatenate([tree[0, :3], tree[1, :3]]).astype(np.float32)
+                assert (box.view(np.uint32) == exp[16:].view(np.uint32)).all(), "%s cone %d box: got %s expected %s" % (name, i, box, exp[16:])
