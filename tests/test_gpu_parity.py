@@ -455,6 +455,31 @@ def test_renderer_api_box_scene(B):
     r.close()
 
 
+def test_two_renderers_on_one_device_do_not_disturb_each_other(B):
+    """The ABI promises independent contexts (include/gpuart_hip.h): two Renderers on the same device, different scenes and frame
+    sizes, their passes interleaved call by call and their pipelines in flight at the same time, each reproduce the reference's
+    golden frames (what gpuart_cli --gpus N relies on, one context per device, and any host that keeps a preview beside a render)."""
+    ga, gb = golden("frames_box_seg5"), golden("frames_scene_pc_seg5")
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    ra = B.Renderer(int(ga["W"]), int(ga["H"]), cam)
+    rb = B.Renderer(int(gb["W"]), int(gb["H"]), cam)
+    for r in (ra, rb):
+        r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+    ra.init_box()
+    rb.set_primitives(scene("scene_pc"))
+    ra.render_direct(); rb.render_direct()
+    na, nb = int(ga["npasses"]) if "npasses" in ga else 8, int(gb["npasses"]) if "npasses" in gb else 2
+    ra.restart_path_tracing(1, na); rb.restart_path_tracing(1, nb)
+    for k in range(max(na, nb)):  # interleaved, nothing observed in between: both contexts have runs in flight
+        if k < na: ra.path_tracing_pass()
+        if k < nb: rb.path_tracing_pass()
+    check_frame(rb.read_radiance(False), gb["pt_acc"], "second renderer, %d passes" % nb)
+    check_frame(ra.read_radiance(False), ga["pt_acc"], "first renderer, %d passes" % na)
+    check_frame(ra.read_direct(), ga["direct"], "first renderer, direct")
+    check_frame(rb.read_direct(), gb["direct"], "second renderer, direct")
+    ra.close(); rb.close()
+
+
 def test_reference_work_mode_counters_match_oracle(B, be, O):
     g = golden("frames_scene_pc_seg5")
     W, H = int(g["W"]), int(g["H"])
