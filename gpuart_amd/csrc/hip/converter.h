@@ -5,8 +5,11 @@
 #include <cmath>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "device_scene.h"
@@ -72,23 +75,33 @@ struct Converter {
             irregular = irregular || !(c.bmin[k] <= c.bmax[k]) || std::isinf(c.bmin[k]) || std::isinf(c.bmax[k]);  // NaN fails <=
     }
 
-    /// Converts the subtree at quad address `addr`. Interior nodes get a 64-byte record (pre-order, so an
-    /// interior lower child's record directly follows its parent's); leaves append their primitives.
-    /// `end` receives the address just past the subtree. Compile (reference src/bvh.cpp:161-222) lays subtrees out
-    /// contiguously in pre-order, so an upper child must start exactly where its sibling's subtree ends: this is
-    /// what rules out overlapping (DAG-shaped) inputs, whose conversion would otherwise take exponential time.
-    bool node(size_t addr, uint32_t depth, Child &out, size_t &end) {
+    /// What the scan keeps of a canonical node: where it lies, the ref its parent stores for it, and (interior nodes) which
+    /// entry of the table its upper child is — its lower child is the next entry (pre-order).
+    struct NodeInfo {
+        uint32_t addr, ref, hi_index, depth;
+    };
+    std::vector<NodeInfo> table;
+    size_t n_recs = 0, n_prims = 0;
+
+    /// Pass 1 — headers only: validates the subtree at quad address `addr` and numbers its records and primitives, in the
+    /// order the device arrays keep them (interior nodes in pre-order, so an interior lower child's record directly follows
+    /// its parent's; leaves append their primitives). `end` receives the address just past the subtree. Compile (reference
+    /// src/bvh.cpp:161-222) lays subtrees out contiguously in pre-order, so an upper child must start exactly where its
+    /// sibling's subtree ends: this is what rules out overlapping (DAG-shaped) inputs, whose conversion would otherwise take
+    /// exponential time. Returns the node's entry in `table`.
+    bool scan(size_t addr, uint32_t depth, uint32_t &index, size_t &end) {
         if (addr + 3 > nq) { err = "node address out of range"; return false; }
         if (depth > 1024) { err = "tree deeper than 1024 levels"; return false; }
         if (depth > max_depth) max_depth = depth;
         num_nodes++;
+        index = (uint32_t)table.size();
+        table.push_back(NodeInfo{(uint32_t)addr, 0, 0, depth});
         const float *b = q + 4 * addr;
-        for (int k = 0; k < 3; k++) { out.bmin[k] = b[k]; out.bmax[k] = b[4 + k]; }
         uint32_t flags = bits(b[8]);
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
-            uint32_t first = (uint32_t)(prims.size() / 3);
-            if (first >= 0x1ffffff0u) { err = "too many primitives"; return false; }
+            if (n_prims >= 0x1ffffff0u) { err = "too many primitives"; return false; }
+            const uint32_t first = (uint32_t)n_prims;
             size_t a = addr + 3;
             static const int LEN[4] = {1, 2, 3, 4};
             bool all_tris = n >= 1 && n <= 2;
@@ -99,36 +112,94 @@ struct Converter {
                 if (type != P_TRIANGLE) all_tris = false;
                 type_mask |= 1u << type;
                 if (a + 1 + LEN[type] > nq) { err = "primitive data out of range"; return false; }
-                float4 rec[3];
-                pack_prim(type, q + 4 * (a + 1), rec);
-                if (i == 0) rec[0].w = fbits(type | (n << 2));  // the first primitive carries the leaf's count
-                prims.push_back(rec[0]); prims.push_back(rec[1]); prims.push_back(rec[2]);
                 a += 1 + LEN[type];
             }
-            if (n == 0) {  // empty leaf (empty scene): one dummy record with count 0
-                prims.push_back(make_float4(0, 0, 0, fbits(0))); prims.push_back(make_float4(0, 0, 0, 0)); prims.push_back(make_float4(0, 0, 0, 0));
-            }
-            out.ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS | (n == 2 ? GD_REF_TWO : 0u) : 0u) | first;
+            n_prims += n ? n : 1;  // an empty leaf (empty scene) keeps one dummy record with count 0
+            table[index].ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS | (n == 2 ? GD_REF_TWO : 0u) : 0u) | first;
             end = a;
             return true;
         }
         uint32_t lo = bits(b[9]), hi = bits(b[10]);
         if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
         if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
-        const size_t r = recs.size() / 4;
-        if (r >= 0x1ffffff0u) { err = "too many nodes"; return false; }
-        recs.resize(recs.size() + 4);
-        Child L, H;
+        if (n_recs >= 0x1ffffff0u) { err = "too many nodes"; return false; }
+        table[index].ref = (uint32_t)n_recs++;
+        uint32_t lo_index, hi_index;
         size_t lo_end = 0;
-        if (!node(lo, depth + 1, L, lo_end)) return false;
+        if (!scan(lo, depth + 1, lo_index, lo_end)) return false;
         if (hi != lo_end) { err = "upper child does not start where the lower subtree ends"; return false; }
-        if (!node(hi, depth + 1, H, end)) return false;
-        note(L); note(H);
-        recs[4 * r + 0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
-        recs[4 * r + 1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
-        recs[4 * r + 2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], fbits(depth < top_depth ? 1u : 0u));
-        recs[4 * r + 3] = make_float4(H.bmax[0], H.bmax[1], H.bmax[2], 0);
-        out.ref = (uint32_t)r;
+        if (!scan(hi, depth + 1, hi_index, end)) return false;
+        table[index].hi_index = hi_index;
+        return true;
+    }
+
+    Child child_of(const NodeInfo &n) const {
+        Child c;
+        const float *b = q + 4 * (size_t)n.addr;
+        for (int k = 0; k < 3; k++) { c.bmin[k] = b[k]; c.bmax[k] = b[4 + k]; }
+        c.ref = n.ref;
+        return c;
+    }
+
+    /// Pass 2 — the entries [from, to) of the table into the device arrays (disjoint writes: any number of threads).
+    /// Returns whether one of the boxes written is irregular.
+    bool fill(size_t from, size_t to) {
+        bool irr = false;
+        auto bad = [](const Child &c) {
+            bool r = false;
+            for (int k = 0; k < 3; k++) r = r || !(c.bmin[k] <= c.bmax[k]) || std::isinf(c.bmin[k]) || std::isinf(c.bmax[k]);  // NaN fails <=
+            return r;
+        };
+        static const int LEN[4] = {1, 2, 3, 4};
+        for (size_t i = from; i < to; i++) {
+            const NodeInfo &n = table[i];
+            const float *b = q + 4 * (size_t)n.addr;
+            if (n.ref & GD_REF_LEAF) {
+                const uint32_t cnt = bits(b[8]) & ~0xE0000000u;
+                float4 *dst = prims.data() + 3 * (size_t)(n.ref & GD_REF_INDEX);
+                size_t a = (size_t)n.addr + 3;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const uint32_t type = bits(q[4 * a]);
+                    pack_prim(type, q + 4 * (a + 1), dst + 3 * k);
+                    if (k == 0) dst[0].w = fbits(type | (cnt << 2));  // the first primitive carries the leaf's count
+                    a += 1 + LEN[type];
+                }
+                if (cnt == 0) { dst[0] = make_float4(0, 0, 0, fbits(0)); dst[1] = make_float4(0, 0, 0, 0); dst[2] = make_float4(0, 0, 0, 0); }
+            } else {
+                const Child L = child_of(table[i + 1]), H = child_of(table[n.hi_index]);
+                irr = irr || bad(L) || bad(H);
+                float4 *r = recs.data() + 4 * (size_t)n.ref;
+                r[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
+                r[1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
+                r[2] = make_float4(H.bmin[0], H.bmin[1], H.bmin[2], fbits(n.depth < top_depth ? 1u : 0u));
+                r[3] = make_float4(H.bmax[0], H.bmax[1], H.bmax[2], 0);
+            }
+        }
+        return irr;
+    }
+
+    /// The whole conversion: scan, then fill on `threads` threads. `root` receives the root's box and ref.
+    bool convert(Child &root, unsigned threads) {
+        uint32_t index;
+        size_t end = 0;
+        table.reserve(nq / 6 + 1);
+        if (!scan(0, 0, index, end)) return false;
+        recs.resize(4 * n_recs);
+        prims.resize(3 * n_prims);
+        root = child_of(table[0]);
+        note(root);
+        const size_t n = table.size();
+        const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 16384));
+        std::vector<char> irr(parts, 0);
+        std::vector<std::thread> pool;
+        auto work = [&](unsigned k) { irr[k] = fill(n * k / parts, n * (size_t)(k + 1) / parts) ? 1 : 0; };
+        for (unsigned k = 1; k < parts; k++) {
+            try { pool.emplace_back(work, k); } catch (const std::system_error &) { work(k); }
+        }
+        work(0);
+        for (auto &t : pool) t.join();
+        for (char v : irr) irregular = irregular || v;
+        std::vector<NodeInfo>().swap(table);
         return true;
     }
 };

@@ -498,9 +498,10 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     cv.q = quads; cv.nq = nquads;
     if (const char *e = getenv("GPUART_HIP_TOP_DEPTH")) cv.top_depth = (uint32_t)atoi(e);
     Converter::Child root;
-    size_t tree_end = 0;
-    if (!cv.node(0, 0, root, tree_end)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
-    cv.note(root);
+    unsigned upload_threads = nquads >= (1u << 20) ? 8u : 1u;  // the fill pass of a big tree on several threads (disjoint writes)
+    if (const char *e = getenv("GPUART_HIP_UPLOAD_THREADS")) upload_threads = (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (!cv.convert(root, upload_threads))
+        return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
     int r;
     if ((r = gpuart_hip_flush(c))) return r;
     if ((r = drain(c))) return r;
