@@ -59,7 +59,7 @@
 #ifdef GD_RUN_TIMELINE
 // diagnostic build (tools/run_timeline.py): per wave, the 100 MHz clock at its start, when the cursor ran dry, at its end,
 // and the lane-rounds it spent traversing (active lanes summed over the rounds of the TRAVERSE loop / rounds)
-__device__ unsigned long long g_run_timeline[8 * 8192];
+__device__ unsigned long long g_run_timeline[12 * 8192];
 __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-time per 25 us bucket
 #endif
 
@@ -95,6 +95,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 
 #ifdef GD_RUN_TIMELINE
     unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start, tl_nready = 0, tl_nshade = 0;
+    unsigned long long tl_tail_trav = 0, tl_tail_other = 0, tl_tail_rounds = 0, tl_tail_trig = 0, tl_mark = tl_start;
     __shared__ unsigned tl_hist[2 * 128];
     tl_hist[lane_id()] = 0; tl_hist[64 + lane_id()] = 0; tl_hist[128 + lane_id()] = 0; tl_hist[192 + lane_id()] = 0;
     const unsigned long long tl_zero = g_run_hist[2 * 128 - 1];  // the host stores the launch's reference clock there (0: use own start)
@@ -273,6 +274,9 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
         if (__ballot(ent != SLOT_INVALID) == 0) break;  // nothing in flight; PRODUCE could not make anything: all done
 
         // ---- TRAVERSE until enough lanes have finished (a lane without an entry is in state DONE) ---------------------
+#ifdef GD_RUN_TIMELINE
+        { const unsigned long long now = wall_clock64(); if (exhausted) { tl_tail_other += now - tl_mark; tl_tail_trig++; } tl_mark = now; }
+#endif
         for (;;) {
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
@@ -289,7 +293,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             }
             const unsigned long long busy = descending | at_leaf;
 #ifdef GD_RUN_TIMELINE
-            tl_lanes += (unsigned long long)__popcll(busy); tl_rounds++;
+            tl_lanes += (unsigned long long)__popcll(busy); tl_rounds++; if (exhausted) tl_tail_rounds++;
             if (!exhausted) { tl_nready += n_ready; tl_nshade += n_shade; }
             {
                 const unsigned long long now = wall_clock64();
@@ -308,12 +312,15 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 if (n_ready || n_shade || !exhausted || finished * RUN_TAIL_DIV >= (uint32_t)__popcll(busy)) break;
             }
         }
+#ifdef GD_RUN_TIMELINE
+        { const unsigned long long now = wall_clock64(); if (exhausted) tl_tail_trav += now - tl_mark; tl_mark = now; }
+#endif
     }
     if (COUNT) flush_counters(wc, segments, gcounters);
 #ifdef GD_RUN_TIMELINE
     if (lane_id() == 0 && blockIdx.x < 8192) {
-        unsigned long long *o = g_run_timeline + 8 * blockIdx.x;
-        o[6] = tl_nready; o[7] = tl_nshade;
+        unsigned long long *o = g_run_timeline + 12 * blockIdx.x;
+        o[6] = tl_nready; o[7] = tl_nshade; o[8] = tl_tail_trav; o[9] = tl_tail_other; o[10] = tl_tail_rounds; o[11] = tl_tail_trig;
         o[0] = tl_start; o[1] = tl_dry; o[2] = wall_clock64(); o[3] = tl_lanes; o[4] = tl_rounds;
         for (int k = 0; k < 256; k++) if (tl_hist[k]) atomicAdd(&g_run_hist[k], (unsigned long long)tl_hist[k]);
         o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);  // XCC_ID, HW_ID

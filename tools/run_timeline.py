@@ -30,7 +30,7 @@ for it in range(3):
         r.path_tracing_pass()
     r.finish()
 n = 4096
-buf = np.zeros((n, 8), np.uint64)
+buf = np.zeros((n, 12), np.uint64)
 L.gpuart_hip_debug_run_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = L.gpuart_hip_debug_run_timeline(r.backend.ctx, buf.ctypes.data_as(C.c_void_p), n)
 assert rc == 0, rc
@@ -45,6 +45,9 @@ print("cursor dry ", q(dry))
 print("end        ", q(end))
 print("tail (end - dry)", q(end - dry))
 print("ready / shade list lengths summed over the rounds before the cursor ran dry / all rounds (lower bound of the mean): %.1f / %.1f" % (buf[:, 6].sum() / buf[:, 4].sum(), buf[:, 7].sum() / buf[:, 4].sum()))
+tt, to, tr, tg = [buf[:, k].astype(np.float64) for k in (8, 9, 10, 11)]
+print("after the cursor ran dry, per wave (medians): %.0f us in traversal rounds (%d rounds, %.2f us each), %.0f us in retire / shade / refill (%d times, %.2f us each)" % (
+    np.median(tt) / 100, int(np.median(tr)), tt.sum() / max(1, tr.sum()) / 100, np.median(to) / 100, int(np.median(tg)), to.sum() / max(1, tg.sum()) / 100))
 print("mean busy lanes per traversal round: %.1f of 64; rounds per wave (median) %d" % (buf[:, 3].sum() / buf[:, 4].sum(), int(np.median(buf[:, 4]))))
 # lane occupancy over time is not recorded; the histogram of wave ends says how the machine empties
 h, edges = np.histogram(end, bins=12)
