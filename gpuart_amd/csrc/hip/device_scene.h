@@ -300,6 +300,14 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool tw
     if (two) {
         const float4 b0 = pa[3], b1 = pa[4], b2 = pa[5];
         tb = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, b0, b1, b2);
+#ifdef GD_LEAF_PROBE  // measurement hook (never in the product build): one more triangle test per pair, result unused
+        {
+            float ox = r.o.x;
+            asm volatile("" : "+v"(ox));
+            const float tc = triangle_t(ox, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, b0, b1, b2);
+            asm volatile("" ::"v"(tc));
+        }
+#endif
     }
     const float ta = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, a0, a1, a2);
     if (ta > 0 && ta < closest) {
