@@ -165,6 +165,21 @@ __global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs
     uint32_t idx = (blockIdx.x * 64 + lane) * 2654435761u;
     float acc = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
+    if (PATTERN == 5) {  // as 1 without the cross-lane moves: every lane follows the index streams of the four owners it loads for
+        uint32_t ix[4];
+        for (int k = 0; k < 4; k++) ix[k] = (blockIdx.x * 64 + 16 * k + (lane >> 2)) * 2654435761u;
+        for (int it = 0; it < iters; it++) {
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = recs[4 * (size_t)(ix[k] & mask) + (lane & 3)];
+            asm volatile("" : "+v"(q[0].w), "+v"(q[1].w), "+v"(q[2].w), "+v"(q[3].w));
+            for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z), "+v"(q[k].w)); acc += (q[k].x + q[k].y) + q[k].z; }
+            const uint32_t h = (__float_as_uint(q[0].w) + __float_as_uint(q[1].w) + __float_as_uint(q[2].w) + __float_as_uint(q[3].w)) & zero;
+#pragma unroll
+            for (int k = 0; k < 4; k++) ix[k] = ix[k] * 1664525u + 1013904223u + h;
+        }
+        idx = ix[0];
+    } else
     if (PATTERN != 4 || (lane & 3) == 0)
     for (int it = 0; it < iters; it++) {
         float4 q[4];
@@ -178,7 +193,7 @@ __global__ void __launch_bounds__(64) k_loadcost(const float4 *__restrict__ recs
             q[k] = recs[a];
         }
         asm volatile("" : "+v"(q[0].w), "+v"(q[1].w), "+v"(q[2].w), "+v"(q[3].w));
-        acc += (q[0].x + q[1].y) + (q[2].z + q[3].x);
+        for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(q[k].x), "+v"(q[k].y), "+v"(q[k].z), "+v"(q[k].w)); acc += (q[k].x + q[k].y) + q[k].z; }
         idx = idx * 1664525u + 1013904223u + ((__float_as_uint(q[0].w) + __float_as_uint(q[1].w) + __float_as_uint(q[2].w) + __float_as_uint(q[3].w)) & zero);
         if (PATTERN == 2) idx = (uint32_t)__shfl((int)idx, 0, 64);
     }
@@ -304,6 +319,8 @@ __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, co
 template <int MODE>
 __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
     using namespace gd;
+    __shared__ float4 s_stage[256];
+    __shared__ uint32_t s_nodes[64];
     uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
     const uint32_t zero = g_zero;
     Ray r;
@@ -316,24 +333,42 @@ __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, ui
     for (int it = 0; it < iters; it++) {
         uint32_t h = 0;
         if (MODE != 2) {
-            const float4 *p = recs + 4 * (size_t)(idx & mask);
-            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            float4 a, b, c, d;
+            if (MODE >= 3) {
+                // cooperative fetch: the four lanes of a quad load the four 16-byte pieces of ONE record per instruction (16 records per
+                // instruction, 64-byte lines whole) straight into LDS; every lane then reads its own record back. MODE 3: + box tests, 4: fetch only
+                const uint32_t lane = threadIdx.x;
+                s_nodes[(lane & 15) * 4 + (lane >> 4)] = idx & mask;
+                const uint4 own = *(const uint4 *)&s_nodes[(lane >> 2) * 4];
+                const uint32_t piece = (lane & 3) ^ ((lane >> 3) & 3);
+                const uint32_t on[4] = {own.x, own.y, own.z, own.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(recs + 4 * (size_t)on[k] + piece),
+                                                     (__attribute__((address_space(3))) void *)(s_stage + 64 * k), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t sw = (lane >> 1) & 3;
+                a = s_stage[4 * lane + (0 ^ sw)]; b = s_stage[4 * lane + (1 ^ sw)]; c = s_stage[4 * lane + (2 ^ sw)]; d = s_stage[4 * lane + (3 ^ sw)];
+            } else {
+                const float4 *p = recs + 4 * (size_t)(idx & mask);
+                a = p[0]; b = p[1]; c = p[2]; d = p[3];
+            }
             asm volatile("" : "+v"(a.w), "+v"(b.w));
             h = __float_as_uint(a.w) + __float_as_uint(b.w);
-            if (MODE == 0) {  // boxes from the record (random bits scaled into a sane range: the arithmetic is what matters)
+            if (MODE == 0 || MODE == 3) {  // boxes from the record (random bits scaled into a sane range: the arithmetic is what matters)
                 lo0 = f3(a.x * 1e-9f, a.y * 1e-9f, a.z * 1e-9f); hi0 = f3(b.x * 1e-9f + 1, b.y * 1e-9f + 1, b.z * 1e-9f + 1);
                 lo1 = f3(c.x * 1e-9f, c.y * 1e-9f, c.z * 1e-9f); hi1 = f3(d.x * 1e-9f + 1, d.y * 1e-9f + 1, d.z * 1e-9f + 1);
             } else {
                 acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + ((c.z + d.x) + (d.y + d.z));
             }
         }
-        if (MODE != 1) {
+        if (MODE != 1 && MODE != 4) {
             float e0, e1;
             const bool h0 = aabb_entry(r, rdiv, lo0, hi0, e0), h1 = aabb_entry(r, rdiv, lo1, hi1, e1);
             acc += (h0 ? e0 : 1.0f) + (h1 ? e1 : 2.0f);
             asm volatile("" : "+v"(lo0.x), "+v"(lo0.y), "+v"(lo0.z), "+v"(hi0.x), "+v"(hi0.y), "+v"(hi0.z), "+v"(acc));
             asm volatile("" : "+v"(lo1.x), "+v"(lo1.y), "+v"(lo1.z), "+v"(hi1.x), "+v"(hi1.y), "+v"(hi1.z));
-            if (MODE == 0) h += __float_as_uint(acc);  // the next address waits for the tests, as a traversal step's does
+            if (MODE == 0 || MODE == 3) h += __float_as_uint(acc);  // the next address waits for the tests, as a traversal step's does
         }
         idx = idx * 1664525u + 1013904223u + (h & zero);
     }
@@ -452,9 +487,10 @@ int main(int argc, char **argv) {
         CHECK(hipMemcpy(recs, h.data(), nrec * 64, hipMemcpyHostToDevice));
         const uint32_t m = (uint32_t)nrec - 1;
         for (int w : {2, 6}) {
-            if (only_node || log2rec != 16u) break;
+            if (only_node ? w != 6 : log2rec != 16u) continue;
             timed(nm("load4x16B_lane_divergent"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<0><<<n, 64>>>(recs, m, 1024, o, c); }, "64 lanes x own 64-B record");
             timed(nm("load4x16B_quad_cooperative"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<1><<<n, 64>>>(recs, m, 1024, o, c); }, "same bytes, a quad reads one record per instruction");
+            timed(nm("load4x16B_quad_cooperative_no_shuffles"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<5><<<n, 64>>>(recs, m, 1024, o, c); }, "as above, addresses without cross-lane moves");
             timed(nm("load4x16B_contiguous"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<2><<<n, 64>>>(recs, m, 1024, o, c); }, "1 KB contiguous per instruction");
             timed(nm("load4x16B_broadcast"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<3><<<n, 64>>>(recs, m, 1024, o, c); }, "all lanes one record");
             timed(nm("load4x16B_16_lanes"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<4><<<n, 64>>>(recs, m, 1024, o, c); }, "16 active lanes, own records");
@@ -487,10 +523,13 @@ int main(int argc, char **argv) {
             timed(nm("node_2x4_32B"), 6, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_node<7><<<n, 64>>>(recs, refs, m, 1024, o, c); });
             CHECK(hipFree(refs));
         }
-        if (log2rec == 8u) {
+        {
             for (int w : {2, 4, 6, 8}) {
-                timed("step_fetch_and_2_box_tests_16KB", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<0><<<n, 64>>>(recs, m, 1024, o, c); });
-                timed("step_fetch_only_16KB", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<1><<<n, 64>>>(recs, m, 1024, o, c); });
+                if (log2rec != 8u && w != 6) continue;
+                timed(nm("step_fetch_and_2_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<0><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed(nm("step_fetch_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<1><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed(nm("step_coop_fetch_and_2_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<3><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed(nm("step_coop_fetch_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<4><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed("step_2_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2><<<n, 64>>>(recs, m, 1024, o, c); });
             }
         }
