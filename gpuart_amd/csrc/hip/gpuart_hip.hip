@@ -561,8 +561,10 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
         TraceTuning dtune = c->tune;
         if (!c->chunk_from_env && c->n_slots / ((size_t)c->direct_waves * 8) < 128) dtune.chunk = 64;
         const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;
+        const bool round_only = c->lean_kernels && !c->exact_boxes && !flat_only && (c->type_mask & ~(uint32_t)GD_ROUND_TYPES) == 0;
         if (c->exact_boxes) k_direct_persistent<GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
         else if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        else if (round_only) k_direct_persistent<GD_ROUND_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
         else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
     }
     HIP_TRY(hipGetLastError());
@@ -640,6 +642,7 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     if (!l.run_cursor) HIP_TRY(hipMalloc(&l.run_cursor, 64));
     const PathBuffers &b = l.pb;
     const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
+    const bool round_only = c->lean_kernels && !c->exact_boxes && !flat_only && (c->type_mask & ~(uint32_t)GD_ROUND_TYPES) == 0;  // spheres + discs
     const bool exact = c->exact_boxes != 0;  // a tree with irregular boxes: the kernel variants with comparison-form box tests
     const uint32_t chunks = b.n_slots * b.batch / BLOCK;
     const dim3 grid(std::min<uint32_t>(c->run_waves, std::max<uint32_t>(1, chunks)));
@@ -656,6 +659,7 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
         else if (c->mode == 4 && exact) k_run<true, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (c->mode == 4) k_run<true, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (flat_only) k_run<false, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (round_only) k_run<false, false, GD_ROUND_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (exact) k_run<false, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else k_run<false, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         HIP_TRY(hipGetLastError());
@@ -691,6 +695,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     if ((r = ensure_segment_counters(c, l, nseg))) return r;
     const PathBuffers &b = l.pb;
     const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
+    const bool round_only = c->lean_kernels && !c->exact_boxes && !flat_only && (c->type_mask & ~(uint32_t)GD_ROUND_TYPES) == 0;  // spheres + discs
     const bool detail = c->timing_level >= 2;
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->shade_waves, b.n_slots * b.batch / BLOCK));  // k_gen / k_shade: grid-stride loops
@@ -703,6 +708,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         int rr;
         if (detail && (rr = begin_timed(c, tt, 1, l.main))) return rr;
         if (flat_only) k_trace<false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+        else if (round_only) k_trace<false, GD_ROUND_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         else if (c->exact_boxes) k_trace<false, GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         else k_trace<false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
         if (detail && (rr = end_timed(c, tt, l.main))) return rr;

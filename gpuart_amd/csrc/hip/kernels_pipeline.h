@@ -173,6 +173,8 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
 // 64 lanes keep traversing; box tests and leaf tests are issued as separate wave-wide phases (leaf code waits until
 // LEAF_LANES lanes need it).
 #define GD_FLAT_TYPES ((1 << gd::P_DISC) | (1 << gd::P_TRIANGLE))
+#define GD_ROUND_TYPES ((1 << gd::P_SPHERE) | (1 << gd::P_DISC))  // sphere scenes (Scene P, the cluster): no triangle, no cone code
+#define GD_LEAN_TYPES(T) ((T) == GD_FLAT_TYPES || (T) == GD_ROUND_TYPES)
 #ifndef GD_TRACE_WAVES
 #define GD_TRACE_WAVES 5  // waves per SIMD the register allocation must allow (<= 96 VGPRs)
 #endif
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
 #define GD_TRACE_WAVES_LEAN 6  // the kernels without cone / sphere code fit 6 waves per SIMD (<= 80 VGPRs)
 #endif
 template <bool COUNT, int TYPES>
-__global__ void __launch_bounds__(BLOCK, TYPES == GD_FLAT_TYPES ? GD_TRACE_WAVES_LEAN : GD_TRACE_WAVES)
+__global__ void __launch_bounds__(BLOCK, GD_LEAN_TYPES(TYPES) ? GD_TRACE_WAVES_LEAN : GD_TRACE_WAVES)
 k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s, int any_shadow, int j, int npaths, float4 *accum,
         uint4 *spill, unsigned long long *gcounters, TraceTuning tune) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
