@@ -100,7 +100,7 @@ struct Converter {
         uint32_t flags = bits(b[8]);
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
-            if (n_prims >= 0x1ffffff0u) { err = "too many primitives"; return false; }
+            if (n_prims >= 0x0ffffff0u) { err = "too many primitives"; return false; }
             const uint32_t first = (uint32_t)n_prims;
             size_t a = addr + 3;
             static const int LEN[4] = {1, 2, 3, 4};
@@ -115,14 +115,14 @@ struct Converter {
                 a += 1 + LEN[type];
             }
             n_prims += n ? n : 1;  // an empty leaf (empty scene) keeps one dummy record with count 0
-            table[index].ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS | (n == 2 ? GD_REF_TWO : 0u) : 0u) | first;
+            table[index].ref = GD_REF_LEAF | (all_tris ? GD_REF_TRIS : n >= 1 && n <= 2 ? GD_REF_SMALL : 0u) | (n == 2 ? GD_REF_TWO : 0u) | first;
             end = a;
             return true;
         }
         uint32_t lo = bits(b[9]), hi = bits(b[10]);
         if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
         if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
-        if (n_recs >= 0x1ffffff0u) { err = "too many nodes"; return false; }
+        if (n_recs >= 0x0ffffff0u) { err = "too many nodes"; return false; }
         table[index].ref = (uint32_t)n_recs++;
         uint32_t lo_index, hi_index;
         size_t lo_end = 0;

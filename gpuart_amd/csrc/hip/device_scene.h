@@ -28,7 +28,8 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #define GD_REF_LEAF 0x80000000u
 #define GD_REF_TRIS 0x40000000u  ///< with GD_REF_LEAF: the leaf holds only triangles, one or two of them
 #define GD_REF_TWO 0x20000000u   ///< with GD_REF_TRIS: two of them (both records are fetched at once; a single-triangle leaf fetches one)
-#define GD_REF_INDEX 0x1fffffffu
+#define GD_REF_SMALL 0x10000000u ///< with GD_REF_LEAF, without GD_REF_TRIS: one or two primitives of any type (GD_REF_TWO: two) — fetched at once like a triangle pair
+#define GD_REF_INDEX 0x0fffffffu
 
 struct Scene {
     const float4 *__restrict__ recs;
@@ -323,6 +324,36 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool tw
     return false;
 }
 
+/// Leaf that holds one or two primitives of any type (what the reference's builder makes of everything but degenerate
+/// input): the leaf's ref says which, so a pair's records are requested together instead of one memory round trip per
+/// primitive, and nothing waits for the count in the first record. Same tests in the same order as the loop of `leaf_test`.
+template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES>
+GD_FN bool leaf_test_small(const Scene &sc, const Ray &r, uint32_t first, bool two, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+    const float4 *pa = sc.prims + 3 * (size_t)first;
+    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+    float tb = -1.0f;
+    F3 p, n; int ptype;
+    if (two) {
+        const float4 b0 = pa[3], b1 = pa[4], b2 = pa[5];
+        prim_hit<TYPES>(r, b0, b1, b2, tb, p, n, ptype);
+        if (COUNT) wc->prims[ptype & 3]++;
+    }
+    float ta;
+    prim_hit<TYPES>(r, a0, a1, a2, ta, p, n, ptype);
+    if (COUNT) wc->prims[ptype & 3]++;
+    if (ta > 0 && ta < closest) {
+        closest = ta;
+        hit_prim = first;
+        if (ANY_HIT) return true;
+    }
+    if (tb > 0 && tb < closest) {
+        closest = tb;
+        hit_prim = first + 1;
+        if (ANY_HIT) return true;
+    }
+    return false;
+}
+
 // ---- traversal stack: short per-lane ring in LDS + spill to global memory -------------------------
 // Entry = (upper child's ref, parent's box-entry parameter, the child's own box-entry parameter).
 // Entries [base, sp) live in the LDS ring (slot = index % RING, one column per
@@ -388,7 +419,9 @@ struct TravStack {
 /// hit (same value: the test is a pure function of node and ray). The upper child's box is tested when
 /// its parent's record is fetched (both boxes share one 64-byte record) and the result waits on the
 /// stack; whether it is *used* is decided exactly where the reference decides it, at pop time.
-enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2, TRAV_LEAF_TRIS = 3, TRAV_LEAF_TRI1 = 5 };  // odd: waiting at a leaf
+// odd: waiting at a leaf; a leaf's state is 1 | its ref's GD_REF_TRIS / GD_REF_TWO / GD_REF_SMALL bits moved down to 8 / 4 / 2
+enum { TRAV_DESCEND = 0, TRAV_LEAF = 1, TRAV_DONE = 2, TRAV_LEAF_ONE = 3, TRAV_LEAF_PAIR = 7, TRAV_LEAF_TRI1 = 9, TRAV_LEAF_TRIS = 13 };
+static_assert((GD_REF_TRIS >> 27) == 8 && (GD_REF_TWO >> 27) == 4 && (GD_REF_SMALL >> 27) == 2, "leaf states are derived from the ref's flag bits");
 
 #define GD_ENTRY_MISS 3.0e+38f  // stack marker: the upper child's box is not hit at all
 
@@ -404,7 +437,7 @@ struct Trav {
 GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
     if (ref & GD_REF_LEAF) {
         t.node = ref & GD_REF_INDEX;
-        t.state = !(ref & GD_REF_TRIS) ? TRAV_LEAF : (ref & GD_REF_TWO) ? TRAV_LEAF_TRIS : TRAV_LEAF_TRI1;
+        t.state = (int)(1u | ((ref >> 27) & 14u));  // TRAV_LEAF, _ONE, _PAIR, _TRI1 or _TRIS (a leaf with more than two primitives keeps all three bits clear)
     } else {
         t.node = ref;
         t.entry = entry;
@@ -513,7 +546,11 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
 template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES>
 GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
     bool stop;
-    if (t.state != TRAV_LEAF) stop = leaf_test_tris<ANY_HIT, COUNT>(sc, r, t.node, t.state == TRAV_LEAF_TRIS, t.closest, t.hit_prim, wc);
+    // (the triangle-mesh kernels keep the loop for their few other leaves — the floor disc —: the pair path there costs the
+    // closest-hit launches 2 % for nothing)
+    constexpr bool SMALL_PATH = (TYPES & 0xF) != ((1 << P_DISC) | (1 << P_TRIANGLE));
+    if (t.state & 8) stop = leaf_test_tris<ANY_HIT, COUNT>(sc, r, t.node, t.state == TRAV_LEAF_TRIS, t.closest, t.hit_prim, wc);
+    else if (SMALL_PATH && t.state != TRAV_LEAF) stop = leaf_test_small<ANY_HIT, COUNT, TYPES>(sc, r, t.node, t.state == TRAV_LEAF_PAIR, t.closest, t.hit_prim, wc);
     else stop = leaf_test<ANY_HIT, COUNT, TYPES>(sc, r, t.node, t.closest, t.hit_prim, wc);
     if (stop && ANY_HIT) {
         t.state = TRAV_DONE;

@@ -246,7 +246,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
-            unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // TRAV_LEAF = 1, TRAV_LEAF_TRIS = 3
+            unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             // leaves are tested once 1/leaf_share of the lanes that still have a ray wait at one (at most leaf_lanes):
             // a wave that is draining its last rays must not hold leaves back for a quorum it can no longer reach

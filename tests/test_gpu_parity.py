@@ -415,6 +415,42 @@ def test_segment_bound_next_to_albedo_powers(B, be, O):
     assert deep > 0
 
 
+@pytest.mark.parametrize("max_levels,min_prims", [(1024, 2), (1024, 5), (4, 2), (1, 2), (7, 1)])
+def test_leaves_of_any_size(B, be, O, max_levels, min_prims):
+    """The uploader routes leaves of one or two primitives through fetch-at-once paths (triangle pairs, pairs of any type) and
+    all others through the counting loop; trees built with other leaf sizes / depth limits than the reference's defaults
+    (`BoundingVolumesHierarchy(prims, maxNumLevels, minPrimitivesPerNode)`, src/bvh.h:78) put every kernel family
+    (triangle + disc, sphere + disc, all types) on every path: direct lighting and path tracing (pipeline, run kernel,
+    reference-work mode, megakernel) against the oracle."""
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    W, H = 72, 40
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    rng = np.random.RandomState(11)
+    mesh = [(S.DISC, [0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 30.0])]
+    for _ in range(60):
+        o = rng.uniform(-1.5, 1.5, 3); o[2] = abs(o[2]) * 0.5 + 0.05
+        mesh.append((S.TRIANGLE, [float(np.float32(v)) for v in np.concatenate([o, o + rng.uniform(-0.5, 0.5, 3), o + rng.uniform(-0.5, 0.5, 3)])]))
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
+    for name, prims in (("mesh", mesh), ("scene_p", S.scene_p()), ("scene_pc", scene("scene_pc"))):
+        tree, _ = O.build_bvh(prims, max_levels=max_levels, min_prims=min_prims)
+        be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+        d = O.render_direct(tree, c, W, H, P)[0]
+        be.render_direct(to_params(B, P))
+        assert_bits(be.read(0)[..., :3].reshape(-1, 3), d[..., :3].reshape(-1, 3), "%s direct" % name)
+        acc = np.zeros((H, W, 4), np.float32)
+        seeds = O.randseeds(3, seed=77)
+        for k in range(3):
+            O.pt_pass(tree, c, W, H, P, seeds[k], 1, acc)
+        for mode in (0, 5, 3, 1, 2):
+            be.set_mode(mode)
+            be.pt_reset()
+            for k in range(3):
+                be.pt_pass(to_params(B, P), seeds[k], 1)
+            assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "%s mode %d" % (name, mode))
+        be.set_mode(0)
+
+
 def test_segment_budget_is_capped(B, be, O):
     """maxSegments beyond GPUART_HIP_MAX_SEGMENTS (1024) is refused instead of allocating counters for 1e9 launches."""
     cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
