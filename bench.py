@@ -244,6 +244,12 @@ def main():
                 be.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
             except B.HipError as e:
                 gather_note = "gpuart_hip_comm_init failed (%s): gathered through torch.distributed point-to-point instead" % e
+            # all ranks must take the same exchange path: one rank's failure moves every rank to the fallback
+            ok = torch.tensor([1 if gather_note is None else 0], dtype=torch.int32, device=xdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0 and gather_note is None:
+                be.comm_destroy()
+                gather_note = "gpuart_hip_comm_init failed on another rank: gathered through torch.distributed point-to-point instead"
         else:
             gather_note = "GPUART_BENCH_BACKEND=%s rehearsal: gathered through host memory" % backend
 
