@@ -571,6 +571,32 @@ def gen_traverse_wild(gl):
         save("traverse_wild_" + name, tree=tree, rs=rs, rd=rd, o0=o0, o1=o1)
 
 
+def gen_traverse_leaves(gl):
+    """CheckIntersectionInclUserSphere on trees with leaves of other sizes than the default build makes (minPrimitivesPerNode 5;
+    depth limits 4, 6 and 1 = the whole scene in the root leaf): the device walks such leaves with its counting loop instead of
+    the fetch-at-once paths. Regular rays + hostile ones; the tree travels in the fixture (same format as traverse_wild)."""
+    rng = np.random.RandomState(9311)
+    body = ("float pos; vec3 p, n; int t; bool ush; CheckIntersectionInclUserSphere(i0.xyz, i1.xyz, BVH, i2, pos, p, n, t, ush);"
+            "if (t >= 0) { O0 = vec4(pos, p); O1 = vec4(n, float(t) + (ush ? 0.5 : 0.0)); } else { O0 = vec4(-1, 0, 0, 0); O1 = vec4(0, 0, 0, -1); }")
+    objs = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "common.glsl", "noise.glsl", "bvh_intersection.glsl", "intersection.glsl"]
+    soup = [(S.DISC, [0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 30.0])]
+    for _ in range(200):
+        o = rng.uniform(-1.5, 1.5, 3); o[2] = abs(o[2]) * 0.5 + 0.05
+        soup.append((S.TRIANGLE, [float(np.float32(v)) for v in np.concatenate([o, o + rng.uniform(-0.5, 0.5, 3), o + rng.uniform(-0.5, 0.5, 3)])]))
+    trees = [("pc_min5", O.build_bvh(scene_tree("scene_pc")[0], min_prims=5)[0]), ("pc_levels4", O.build_bvh(scene_tree("scene_pc")[0], max_levels=4)[0]),
+             ("p_root_leaf", O.build_bvh(S.scene_p(), max_levels=1)[0]), ("soup_levels6", O.build_bvh(soup, max_levels=6)[0])]
+    for name, tree in trees:
+        n = 2048
+        rs = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32); rs[:, 2] = np.abs(rs[:, 2])
+        aim = rng.uniform(-1.2, 1.2, (n, 3)); aim[:, 2] = np.abs(aim[:, 2])
+        rd = ((aim - rs) * rng.uniform(0.05, 2.0, (n, 1))).astype(np.float32)
+        inject(rng, [rs[3 * n // 4:], rd[3 * n // 4:]], 0.7)   # last quarter: hostile rays
+        us = np.tile(np.array([-0.4, 0, 0.2, 0.25], np.float32), (n, 1))
+        o0, o1 = glref.run_probe_big(gl, body, objs, [pad4(rs), pad4(rd), us], 2, bvh=tree, decls=D_INCL, chunk=2048)
+        print("traverse_leaves %s: %d quads, %d of %d rays hit" % (name, len(tree), int((o1[:, 3] >= 0).sum()), n))
+        save("traverse_wild_" + name, tree=tree, rs=rs, rd=rd, o0=o0, o1=o1)
+
+
 def gen_frames(gl):
     seeds = O.randseeds(16)
     for name, (W, H), camsel, segs in [("box", (128, 128), S.DEFAULT_CAMERA, [5, 1, 4, 8]),
@@ -701,7 +727,7 @@ def gen_cluster_tree(gl):
 
 
 SECTIONS = dict(scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

@@ -228,11 +228,12 @@ def test_traversal(be, O, name):
         assert ((a0[:, 0] > 0) == bvh_hit).all()
 
 
-@pytest.mark.parametrize("name", ["scene_pc", "wild_42874", "wild_7", "wild2_5"])
+@pytest.mark.parametrize("name", ["scene_pc", "wild_42874", "wild_7", "wild2_5", "pc_min5", "pc_levels4", "p_root_leaf", "soup_levels6"])
 def test_traversal_with_hostile_rays_and_trees(be, name):
     """The device traversal (closest hit incl. the user sphere, radius 0.25) with hostile rays on a regular tree and with regular +
     hostile rays on the trees of wild scenes (irregular boxes -> the exact box test; a 200-level chain -> the spilled stack),
-    against the reference's CheckIntersectionInclUserSphere on llvmpipe (make_golden.py traverse_wild; the tree is in the fixture)."""
+    and on trees with other leaf sizes than the default build's (the counting leaf loop), against the reference's
+    CheckIntersectionInclUserSphere on llvmpipe (make_golden.py traverse_wild / traverse_leaves; the tree is in the fixture)."""
     g = golden("traverse_wild_" + name)
     be.upload_bvh(g["tree"])
     o0, o1 = be.test_traverse(pad4(g["rs"]), pad4(g["rd"]), (-0.4, 0.0, 0.2, 0.25))
@@ -819,6 +820,33 @@ def test_scheduling_knobs_never_change_the_result(B, O, env, monkeypatch):
     finally:
         b.close()
     assert_bits(got[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "knobs %s" % env)
+
+
+@pytest.mark.parametrize("sc,npaths", [("scene_d", 1), ("scene_p", 1), ("scene_pc", 3)])
+def test_passes_observed_one_by_one(B, O, sc, npaths):
+    """The reference's interactive loop (src/main.cpp:549-599): one pass per GUI frame, observed after each. Every pass is then its
+    own run of the persistent kernel: the accumulator after every pass equals the oracle's, also across a reset, a camera change and
+    a resize (1 and 3 paths per pixel and pass)."""
+    W, H = 200, 104
+    cam = dict(S.BENCH_CAMERA if sc == "scene_d" else S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    tree, _ = O.build_bvh(scene(sc))
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    b = B.Backend(0)
+    try:
+        for (w, h, dx) in ((W, H, 0.0), (W, H, 0.3), (W - 56, H + 8, 0.3)):
+            pos = [cam["pos"][0] + dx, cam["pos"][1], cam["pos"][2]]
+            c = O.camera(pos, cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], w, h)
+            P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 8, 0.01)
+            b.resize(w, h); b.upload_bvh(tree); b.set_camera(c)
+            b.pt_reset()
+            seeds = O.randseeds(5, seed=31)
+            acc = np.zeros((h, w, 4), np.float32)
+            for k in range(5):
+                O.pt_pass(tree, c, w, h, P, seeds[k], npaths, acc, nthreads=8)
+                b.pt_pass(to_params(B, P), seeds[k], npaths)
+                assert_bits(b.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "%s %dx%d pass %d" % (sc, w, h, k))
+    finally:
+        b.close()
 
 
 def test_random_cases_vs_reference_goldens(B, be, O):

@@ -94,10 +94,11 @@ def _bits_or_nan(got, exp, what):
                                                                                          got[bad][0], exp[bad][0])
 
 
-@pytest.mark.parametrize("name", ["scene_pc", "wild_42874", "wild_7", "wild2_5"])
+@pytest.mark.parametrize("name", ["scene_pc", "wild_42874", "wild_7", "wild2_5", "pc_min5", "pc_levels4", "p_root_leaf", "soup_levels6"])
 def test_traversal_with_hostile_rays_and_trees(name):
     """CheckIntersectionInclUserSphere with hostile rays on a regular tree and with regular + hostile rays on the trees of wild
-    scenes (irregular boxes, a 200-level chain), user sphere of radius 0.25, against the reference's GLSL on llvmpipe."""
+    scenes (irregular boxes, a 200-level chain) and on trees with other leaf sizes than the default build's (5 primitives per
+    leaf, depth limits 4 / 6 / 1 = everything in the root leaf), user sphere of radius 0.25, against the reference's GLSL on llvmpipe."""
     g = golden("traverse_wild_" + name)
     o0, o1 = O.traverse(g["tree"], pad4(g["rs"]), pad4(g["rd"]), (-0.4, 0.0, 0.2, 0.25))
     got, exp = np.concatenate([o0, o1], 1), np.concatenate([g["o0"], g["o1"]], 1)
