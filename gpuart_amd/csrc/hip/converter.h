@@ -19,10 +19,19 @@ namespace {
 using namespace gd;
 
 // ---- canonical tree -> device layout ---------------------------------------------------------------
+/// std::allocator whose value-less construct() leaves trivial elements uninitialised: the device arrays are touched for the first
+/// time by the threads that fill them (every element is written), not zeroed by one thread beforehand.
+template <class T>
+struct UninitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = UninitAlloc<U>; };
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+
 struct Converter {
     const float *q;
     size_t nq;
-    std::vector<float4> recs, prims;
+    std::vector<float4, UninitAlloc<float4>> recs, prims;
     size_t num_nodes = 0;
     uint32_t type_mask = 0;
     uint32_t max_depth = 0;

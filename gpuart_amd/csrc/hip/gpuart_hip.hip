@@ -327,8 +327,8 @@ int end_timed(gpuart_hip_ctx *c, TimedLaunch &t, hipStream_t stream = nullptr) {
     return 0;
 }
 
-template <class T>
-int upload_vec(gpuart_hip_ctx *c, T *&dst, const std::vector<T> &v) {
+template <class T, class A>
+int upload_vec(gpuart_hip_ctx *c, T *&dst, const std::vector<T, A> &v) {
     if (dst) { (void)hipFree(dst); dst = nullptr; }
     size_t bytes = (v.size() + 4) * sizeof(T);  // a little slack past the end
     HIP_TRY(hipMalloc(&dst, bytes));

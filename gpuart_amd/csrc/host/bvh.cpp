@@ -50,7 +50,6 @@ BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &pri
         items[i] = Item{{p->GetXmin(), p->GetYmin(), p->GetZmin()}, {p->GetXmax(), p->GetYmax(), p->GetZmax()}, primitives[i]};
     }
     Subtree root;
-    root.nodes.reserve(primitives.size() + 1);
     // threads are worth starting when the scene is large enough to pay for them
     std::atomic<int> spare(primitives.size() >= 16384 ? build_threads() - 1 : 0);
     const bool timing = std::getenv("GPUART_HOST_TIMING") != nullptr;
@@ -58,8 +57,7 @@ BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &pri
     SubdivideParallel(root, items, 0, items.size(), 0, maxNumLevels, minPrimitivesPerNode, spare);
     const auto t1 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < items.size(); i++) primitives[i] = items[i].p;  // the reference leaves the caller's list sorted too
-    Nodes = std::move(root.nodes);
-    Depth = root.depth;
+    Assemble(root, primitives.size() >= 16384 ? build_threads() : 1);
     StoreLeaves(items, primitives.size() >= 16384 ? build_threads() : 1);
     if (timing)
         fprintf(stderr, "[gpuart] BVH build: subdivide %.1f ms, leaf payloads %.1f ms (%d threads)\n",
@@ -86,16 +84,24 @@ void parallel_parts(int parts, F body) {
 
 void BoundingVolumesHierarchy::StoreLeaves(const std::vector<Item> &prims, int threads) {
     // payload length of every leaf: per primitive one type quad + 1..4 data quads (reference src/core.h:72-80)
-    size_t cursor = 0;
-    for (Node &n : Nodes) {
-        n.dataBegin = cursor;
-        for (uint32_t i = 0; i < n.count; i++) cursor += prims[n.primFirst + i].p->GetBVHDataLength();
-        n.dataEnd = cursor;
-    }
-    LeafData.assign(cursor, 0.0f);
     const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, Nodes.size() / 4096));
+    std::vector<size_t> partLen((size_t)parts + 1, 0);
+    parallel_parts(parts, [&](int k) {  // lengths relative to the part's start ...
+        const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
+        size_t cursor = 0;
+        for (size_t i = a; i < b; i++) {
+            Node &n = Nodes[i];
+            n.dataBegin = cursor;
+            for (uint32_t j = 0; j < n.count; j++) cursor += prims[n.primFirst + j].p->GetBVHDataLength();
+            n.dataEnd = cursor;
+        }
+        partLen[(size_t)k + 1] = cursor;
+    });
+    for (int k = 0; k < parts; k++) partLen[(size_t)k + 1] += partLen[(size_t)k];  // ... made absolute below
+    LeafData.resize(partLen[(size_t)parts]);  // (not zeroed: every float is written by the part that owns it)
     parallel_parts(parts, [&](int k) {
         const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
+        for (size_t i = a; i < b; i++) { Nodes[i].dataBegin += partLen[(size_t)k]; Nodes[i].dataEnd += partLen[(size_t)k]; }
         Primitive::Data one;
         for (size_t i = a; i < b; i++) {
             const Node &n = Nodes[i];
@@ -112,15 +118,32 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
                                            unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
                                            size_t &split, std::atomic<int> &spareThreads, Scratch &scratch) {
     if (level > out.depth) out.depth = level;
+    // the passes over a very large node's range (box, keys, permutation) run on several threads: with the subtrees assembled
+    // once and the sort parallel, they are what is left of the top levels' critical path
+    const int wide = to - from >= 262144 ? std::min(8, std::max(1, build_threads() / 4)) : 1;
     {
         Node &n = out.nodes[self];
         n.higher = 0; n.count = 0; n.primFirst = 0; n.dataBegin = n.dataEnd = 0;
+        struct Box { float lo[3], hi[3]; };
+        std::vector<Box> part((size_t)wide);
+        parallel_parts(wide, [&](int w) {
+            Box b;
+            for (int k = 0; k < 3; k++) { b.lo[k] = 99.0e+29f; b.hi[k] = -99.0e+29f; }
+            const size_t a = from + (to - from) * (size_t)w / wide, e = from + (to - from) * (size_t)(w + 1) / wide;
+            for (size_t i = a; i < e; i++)
+                for (int k = 0; k < 3; k++) {
+                    const float lo = prims[i].lo[k], hi = prims[i].hi[k];
+                    if (lo < b.lo[k]) b.lo[k] = lo;
+                    if (hi > b.hi[k]) b.hi[k] = hi;
+                }
+            part[(size_t)w] = b;
+        });
+        // (the same running minimum / maximum: `<` and `>` keep the first of equal values and skip NaN, in parts as in one pass)
         for (int k = 0; k < 3; k++) { n.lo[k] = 99.0e+29f; n.hi[k] = -99.0e+29f; }
-        for (size_t i = from; i < to; i++)
+        for (int w = 0; w < wide; w++)
             for (int k = 0; k < 3; k++) {
-                const float lo = prims[i].lo[k], hi = prims[i].hi[k];
-                if (lo < n.lo[k]) n.lo[k] = lo;
-                if (hi > n.hi[k]) n.hi[k] = hi;
+                if (part[(size_t)w].lo[k] < n.lo[k]) n.lo[k] = part[(size_t)w].lo[k];
+                if (part[(size_t)w].hi[k] > n.hi[k]) n.hi[k] = part[(size_t)w].hi[k];
             }
     }
     const float xr = out.nodes[self].hi[0] - out.nodes[self].lo[0], yr = out.nodes[self].hi[1] - out.nodes[self].lo[1],
@@ -145,11 +168,19 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
         const size_t n = to - from;
         if (scratch.keys.size() < n) { scratch.keys.resize(n); scratch.items.resize(n); }
         SortKey *keys = scratch.keys.data();
-        for (size_t i = 0; i < n; i++) keys[i] = SortKey{prims[from + i].lo[axis] + prims[from + i].hi[axis], (uint32_t)i};
+        parallel_parts(wide, [&](int w) {
+            for (size_t i = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide; i < e; i++)
+                keys[i] = SortKey{prims[from + i].lo[axis] + prims[from + i].hi[axis], (uint32_t)i};
+        });
         ExactSort::Sort(keys, keys + n, spareThreads);
         Item *sorted = scratch.items.data();
-        for (size_t i = 0; i < n; i++) sorted[i] = prims[from + keys[i].index];
-        std::copy(sorted, sorted + n, prims.begin() + from);
+        parallel_parts(wide, [&](int w) {
+            for (size_t i = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide; i < e; i++) sorted[i] = prims[from + keys[i].index];
+        });
+        parallel_parts(wide, [&](int w) {
+            const size_t a = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide;
+            std::copy(sorted + a, sorted + e, prims.begin() + from + a);
+        });
     }
 
     const double middle = out.nodes[self].lo[axis] + 0.5 * range;
@@ -192,7 +223,9 @@ void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item>
     size_t split;
     if (PrepareNode(out, 0, prims, from, to, level, maxNumLevels, minPrimitivesPerNode, split, spareThreads, scratch)) return;
     { Scratch().swap(scratch); }  // the halves bring their own
-    Subtree lo, hi;
+    out.lo.reset(new Subtree());
+    out.hi.reset(new Subtree());
+    Subtree &lo = *out.lo, &hi = *out.hi;
     auto buildLo = [&] { SubdivideParallel(lo, prims, from, split, level + 1, maxNumLevels, minPrimitivesPerNode, spareThreads); };
     std::future<void> task;
     // a lopsided split (one dominating primitive) is not worth a thread
@@ -207,25 +240,56 @@ void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item>
             spareThreads.fetch_add(1);
     }
     SubdivideParallel(hi, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, spareThreads);
-    if (task.valid()) task.get();
-    else buildLo();
-    out.nodes.reserve(1 + lo.nodes.size() + hi.nodes.size());
-    auto splice = [&out](Subtree &sub, bool isLower) {
-        const uint32_t base = (uint32_t)out.nodes.size();
-        out.nodes.insert(out.nodes.end(), sub.nodes.begin(), sub.nodes.end());
-        Node *n = out.nodes.data() + base;
-        n[0].parent = 0; n[0].isLower = isLower;
-        if (n[0].higher) n[0].higher += base;
-        for (size_t i = 1; i < sub.nodes.size(); i++) {
-            n[i].parent += base;
-            if (n[i].higher) n[i].higher += base;
+    if (task.valid()) {
+        spareThreads.fetch_add(1);  // while this thread waits, another may be started in its place
+        task.get();
+        spareThreads.fetch_sub(1);
+    } else
+        buildLo();
+}
+
+void BoundingVolumesHierarchy::Assemble(Subtree &root, int threads) {
+    // pre-order walk over the pieces: where each one's first node goes
+    std::vector<Subtree *> pieces;
+    struct Link { Subtree *piece; size_t parentNode; bool isLower; };
+    std::vector<Link> links;
+    size_t total = 0;
+    unsigned depth = 0;
+    {
+        std::vector<Link> stack{{&root, 0, false}};
+        while (!stack.empty()) {
+            const Link l = stack.back();
+            stack.pop_back();
+            l.piece->base = total;
+            total += l.piece->nodes.size();
+            if (l.piece->depth > depth) depth = l.piece->depth;
+            links.push_back(l);
+            if (l.piece->lo) {  // the upper half is laid out after the whole lower one
+                stack.push_back(Link{l.piece->hi.get(), l.piece->base, false});
+                stack.push_back(Link{l.piece->lo.get(), l.piece->base, true});
+            }
         }
-        std::vector<Node>().swap(sub.nodes);
-        if (sub.depth > out.depth) out.depth = sub.depth;
-    };
-    splice(lo, true);
-    out.nodes[0].higher = (uint32_t)out.nodes.size();
-    splice(hi, false);
+    }
+    Nodes.resize(total);
+    Depth = depth;
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, links.size()));
+    parallel_parts(parts, [&](int k) {
+        for (size_t li = (size_t)k; li < links.size(); li += (size_t)parts) {
+            const Link &l = links[li];
+            const Subtree &p = *l.piece;
+            const uint32_t base = (uint32_t)p.base;
+            Node *n = Nodes.data() + p.base;
+            std::copy(p.nodes.begin(), p.nodes.end(), n);
+            n[0].parent = (uint32_t)l.parentNode;
+            n[0].isLower = l.isLower;
+            if (p.lo) n[0].higher = (uint32_t)p.hi->base;  // a forked node: its upper half is a piece of its own
+            else if (n[0].higher) n[0].higher += base;
+            for (size_t i = 1; i < p.nodes.size(); i++) {
+                n[i].parent += base;
+                if (n[i].higher) n[i].higher += base;
+            }
+        }
+    });
 }
 
 void BoundingVolumesHierarchy::Compile(Primitive::Data &out) const {

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdint>
 #include <iosfwd>
+#include <memory>
 #include <vector>
 
 #include "core.h"
@@ -73,11 +74,25 @@ private:
     struct Subtree {
         std::vector<Node> nodes;
         unsigned depth = 0;  ///< deepest level reached (absolute)
+        /// A large node built in parallel keeps only itself in `nodes`; its halves are subtrees of their own, put together
+        /// once, at the end (Assemble): nothing is copied level by level.
+        std::unique_ptr<Subtree> lo, hi;
+        size_t base = 0;     ///< index of nodes[0] in the finished tree (Assemble)
     };
+    /// Lays the pieces of a parallel build out in pre-order as `Nodes` (indices made absolute; several threads).
+    void Assemble(Subtree &root, int threads);
     /// Serialises the primitives of all leaves into LeafData (Primitive::StoreIntoBVH), several threads on node ranges.
     void StoreLeaves(const std::vector<Item> &prims, int threads);
     std::vector<Node> Nodes;          ///< pre-order
-    std::vector<float> LeafData;      ///< serialised primitives of all leaves, in leaf order
+    /// std::allocator whose value-less construct() leaves trivial elements uninitialised: a large buffer is then touched for the
+    /// first time by the threads that fill it, not zeroed by one thread beforehand.
+    template <class T>
+    struct UninitAlloc : std::allocator<T> {
+        template <class U> struct rebind { using other = UninitAlloc<U>; };
+        template <class U> void construct(U *p) { ::new ((void *)p) U; }
+        template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+    };
+    std::vector<float, UninitAlloc<float>> LeafData;  ///< serialised primitives of all leaves, in leaf order
     size_t NumPrimitives = 0;
     unsigned Depth = 0;
 

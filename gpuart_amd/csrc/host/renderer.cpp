@@ -165,6 +165,7 @@ void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInf
     const auto tAll = t0;
     if (printInfo) std::cout << "Constructing BVH tree of " << primitives.size() << " primitives... " << std::flush;
     Tree = BoundingVolumesHierarchy(primitives, 1024, 2);  // reference src/renderer.cpp:454
+    const auto tBuilt = std::chrono::high_resolution_clock::now();
     if (printInfo) {
         std::cout << "done (" << Utils::TimeElapsed(t0) << ")." << std::endl;
         std::cout << "Compiling BVH tree... " << std::flush;
@@ -172,13 +173,17 @@ void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInf
     }
     Primitive::Data compiled;
     Tree.Compile(compiled);
+    const auto tCompiled = std::chrono::high_resolution_clock::now();
     if (printInfo) std::cout << "done (" << Utils::TimeElapsed(t0) << ").\n";
     if (!Backend || !Check(gpuart_hip_upload_bvh(Backend, compiled.data(), compiled.size() / RGBA_ELEMS), "uploading the BVH"))
         IsOK = false;
     if (printInfo) std::cout << "Compiled tree occupies " << ByteCount{compiled.size() * sizeof(float)} << "." << std::endl;
-    if (std::getenv("GPUART_HOST_TIMING"))
-        fprintf(stderr, "[gpuart] Renderer::SetPrimitives(%zu primitives): %.1f ms (build + compile + re-layout + upload)\n",
-                primitives.size(), std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - tAll).count());
+    if (std::getenv("GPUART_HOST_TIMING")) {
+        const auto tEnd = std::chrono::high_resolution_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[gpuart] Renderer::SetPrimitives(%zu primitives): %.1f ms (build %.1f + compile %.1f + re-layout and upload %.1f)\n",
+                primitives.size(), ms(tAll, tEnd), ms(tAll, tBuilt), ms(tBuilt, tCompiled), ms(tCompiled, tEnd));
+    }
     ResetPathTracing();
 }
 
