@@ -125,7 +125,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
         Node &n = out.nodes[self];
         n.higher = 0; n.count = 0; n.primFirst = 0; n.dataBegin = n.dataEnd = 0;
         struct Box { float lo[3], hi[3]; };
-        std::vector<Box> part((size_t)wide);
+        Box part[8];  // wide <= 8
         parallel_parts(wide, [&](int w) {
             Box b;
             for (int k = 0; k < 3; k++) { b.lo[k] = 99.0e+29f; b.hi[k] = -99.0e+29f; }
@@ -136,14 +136,14 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
                     if (lo < b.lo[k]) b.lo[k] = lo;
                     if (hi > b.hi[k]) b.hi[k] = hi;
                 }
-            part[(size_t)w] = b;
+            part[w] = b;
         });
         // (the same running minimum / maximum: `<` and `>` keep the first of equal values and skip NaN, in parts as in one pass)
         for (int k = 0; k < 3; k++) { n.lo[k] = 99.0e+29f; n.hi[k] = -99.0e+29f; }
         for (int w = 0; w < wide; w++)
             for (int k = 0; k < 3; k++) {
-                if (part[(size_t)w].lo[k] < n.lo[k]) n.lo[k] = part[(size_t)w].lo[k];
-                if (part[(size_t)w].hi[k] > n.hi[k]) n.hi[k] = part[(size_t)w].hi[k];
+                if (part[w].lo[k] < n.lo[k]) n.lo[k] = part[w].lo[k];
+                if (part[w].hi[k] > n.hi[k]) n.hi[k] = part[w].hi[k];
             }
     }
     const float xr = out.nodes[self].hi[0] - out.nodes[self].lo[0], yr = out.nodes[self].hi[1] - out.nodes[self].lo[1],
