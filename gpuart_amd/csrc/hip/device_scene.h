@@ -383,25 +383,31 @@ struct TravStack {
     uint32_t spill_stride;   ///< total lanes of the launch
     uint32_t sp, base;
     GD_FN void reset() { sp = 0; base = 0; }
-    GD_FN void push(StackEntry e) {
+    /// `writer`: this lane performs the stores. A ray that several lanes carry as identical replicas (the thin-wave modes
+    /// below) has ONE column; every replica keeps sp / base and reads the column, only the first one writes it.
+    GD_FN void push(StackEntry e, bool writer = true) {
         if (sp - base == GD_RING) {
             uint32_t o = GD_RING_SLOT(base) * ring_stride;
             uint2 a = ring_a[o];
-            spill[(size_t)base * spill_stride] = make_uint4(a.x, a.y, __float_as_uint(ring_b[o]), 0);
+            if (writer) spill[(size_t)base * spill_stride] = make_uint4(a.x, a.y, __float_as_uint(ring_b[o]), 0);
             base++;
         }
         uint32_t o = GD_RING_SLOT(sp) * ring_stride;
-        ring_a[o] = make_uint2(e.ref, __float_as_uint(e.pe));
-        ring_b[o] = e.he;
+        if (writer) {
+            ring_a[o] = make_uint2(e.ref, __float_as_uint(e.pe));
+            ring_b[o] = e.he;
+        }
         sp++;
     }
-    GD_FN StackEntry pop() {  // precondition: sp > 0
+    GD_FN StackEntry pop(bool writer = true) {  // precondition: sp > 0
         if (sp == base) {
             base--;
             uint4 v = spill[(size_t)base * spill_stride];
             uint32_t o = GD_RING_SLOT(base) * ring_stride;
-            ring_a[o] = make_uint2(v.x, v.y);
-            ring_b[o] = __uint_as_float(v.z);
+            if (writer) {
+                ring_a[o] = make_uint2(v.x, v.y);
+                ring_b[o] = __uint_as_float(v.z);
+            }
         }
         sp--;
         uint32_t o = GD_RING_SLOT(sp) * ring_stride;
@@ -447,10 +453,10 @@ GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
 
 /// Returns to the nearest pending upper child that is still worth visiting (or finishes).
 template <bool COUNT>
-GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc) {
+GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true) {
     for (;;) {
         if (st.sp == 0) { t.state = TRAV_DONE; return; }
-        StackEntry e = st.pop();
+        StackEntry e = st.pop(writer);
         if (e.pe > t.closest) continue;   // the reference's parent re-test fails: skip the upper child
         if (COUNT) wc->nodes++;           // the reference tests the upper child's box now
         if (e.he > t.closest) continue;   // box missed (GD_ENTRY_MISS), or entered beyond the closest hit
@@ -557,6 +563,101 @@ GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st,
         return;
     }
     trav_pop<COUNT>(t, st, wc);
+}
+
+// ---- thin-wave modes: M = 2 or 4 lanes per ray ----------------------------------------------------------------------
+// A persistent wave that is draining its last rays still pays for whole instructions: a wave64 VALU instruction takes its
+// issue slots and a 16-byte load instruction its >= 16 cycles in the address unit however few lanes are active, and a node
+// visit is a chain of ~200 dependent instructions. When a wave holds at most 64 / M rays, every ray is therefore carried
+// by M adjacent lanes as IDENTICAL replicas (same registers, same control flow, one stack column written by the first
+// replica), and only the two expensive parts of a visit are split between them:
+//   * the node record: replica j of a quad loads quad j of the record (one load instruction per wave instead of four),
+//     tests the three planes its quad names — the minimum faces of the lower child's box, its maximum faces, and the same
+//     for the upper child — against the partner's quad, and the six candidates of a box are reduced with a quad-permute
+//     min. Same operands, same operations as `aabb_entry`: med3 is symmetric in its bounds, and a minimum of non-NaN
+//     values does not depend on the order it is taken in (the sign of a zero entry parameter may differ; entry parameters
+//     are only ever compared). A pair (M = 2) gives each lane one whole box;
+//   * a leaf of one or two triangles: each half of the group tests one triangle.
+// Everything else (stack, descent, pops, the generic leaf loops) runs replicated and unchanged, so the walk visits the same
+// nodes in the same order and returns the same bits. Fast-form boxes only (trees with irregular boxes stay in wide mode).
+
+/// quad_perm controls of v_mov_b32_dpp: lane i of every quad reads lane p_i of the same quad.
+#define GD_QUAD_PERM(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
+template <int CTRL>
+GD_FN uint32_t quad_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+GD_FN float quad_f(float v) { return __uint_as_float(quad_u<CTRL>(__float_as_uint(v))); }
+
+/// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them). Precondition: DESCEND.
+template <int M>
+GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub) {
+    static_assert(M == 2 || M == 4, "two or four lanes per ray");
+    const float4 *rec = sc.recs + 4 * (size_t)t.node;
+    const float INF = __builtin_inff();
+    float e;  // this lane's box: entry parameter, GD_ENTRY_MISS when not hit
+    uint32_t ref_lo, ref_hi;
+    if (M == 4) {
+        float4 mine = rec[sub];  // 0: lo.min | lo ref, 1: lo.max | hi ref, 2: hi.min, 3: hi.max
+        asm volatile("" : "+v"(mine.w));  // keep the ref in the 16-byte load (see trav_step_box)
+        const F3 other = f3(quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.x), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.y), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.z));
+        const bool inside = within(ro.x, mine.x, other.x) & within(ro.y, mine.y, other.y) & within(ro.z, mine.z, other.z);
+        const float cx = face_candidate((mine.x - ro.x) * rdiv.x, ro.y, rd.y, mine.y, other.y, ro.z, rd.z, mine.z, other.z);
+        const float cy = face_candidate((mine.y - ro.y) * rdiv.y, ro.x, rd.x, mine.x, other.x, ro.z, rd.z, mine.z, other.z);
+        const float cz = face_candidate((mine.z - ro.z) * rdiv.z, ro.x, rd.x, mine.x, other.x, ro.y, rd.y, mine.y, other.y);
+        const float half = fminf(fminf(cx, cy), cz);
+        const float best = fminf(half, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(half));
+        e = inside ? -1.0f : fminf(best, 1.0e+19f);
+        e = (inside | (best < INF)) ? e : GD_ENTRY_MISS;
+        ref_lo = quad_u<GD_QUAD_PERM(0, 0, 0, 0)>(__float_as_uint(mine.w));
+        ref_hi = quad_u<GD_QUAD_PERM(1, 1, 1, 1)>(__float_as_uint(mine.w));
+    } else {
+        float4 bmin = rec[2 * sub], bmax = rec[2 * sub + 1];  // sub 0: the lower child's box (and both refs), 1: the upper child's
+        asm volatile("" : "+v"(bmin.w), "+v"(bmax.w));
+        float pos;
+        const bool hit = aabb_entry(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos);
+        e = hit ? pos : GD_ENTRY_MISS;
+        ref_lo = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmin.w));
+        ref_hi = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmax.w));
+    }
+    const float el = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(e) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(e);
+    const float eh = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(e) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(e);
+    const bool writer = sub == 0;
+    if (eh != GD_ENTRY_MISS) {
+        StackEntry s;
+        s.ref = ref_hi; s.pe = t.entry; s.he = eh;
+        st.push(s, writer);
+    }
+    if (el != GD_ENTRY_MISS && !(el > t.closest)) {
+        trav_enter(t, ref_lo, el);
+        return;
+    }
+    trav_pop<false>(t, st, nullptr, writer);
+}
+
+/// The pending leaf of a ray carried by M replicas, then the pop. A leaf of one or two triangles is split between the halves
+/// of the group; every other leaf runs replicated through the code of `trav_step_leaf`.
+template <int M, int TYPES>
+GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub) {
+    const bool writer = sub == 0;
+    constexpr bool SMALL_PATH = (TYPES & 0xF) != ((1 << P_DISC) | (1 << P_TRIANGLE));
+    const Ray r{ro, rd};
+    if (t.state & 8) {
+        const bool two = t.state == TRAV_LEAF_TRIS;
+        const bool second = (M == 4 ? (sub >> 1) : sub) != 0;
+        const float4 *pa = sc.prims + 3 * (size_t)t.node + ((second && two) ? 3 : 0);
+        const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+        const float tt = triangle_t(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, a0, a1, a2);
+        const float ta = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(tt) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(tt);
+        float tb = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(tt) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(tt);
+        tb = two ? tb : -1.0f;
+        if (ta > 0 && ta < t.closest) { t.closest = ta; t.hit_prim = t.node; }
+        if (tb > 0 && tb < t.closest) { t.closest = tb; t.hit_prim = t.node + 1; }
+    } else if (SMALL_PATH && t.state != TRAV_LEAF) {
+        leaf_test_small<false, false, TYPES>(sc, r, t.node, t.state == TRAV_LEAF_PAIR, t.closest, t.hit_prim, nullptr);
+    } else {
+        leaf_test<false, false, TYPES>(sc, r, t.node, t.closest, t.hit_prim, nullptr);
+    }
+    trav_pop<false>(t, st, nullptr, writer);
 }
 
 /// Runs one query to completion (megakernels and test hooks).

@@ -28,6 +28,8 @@
 // bit-identical to the launch pipeline: each path's arithmetic is the same sequence of the same functions, its colour
 // goes to its own pixel of the pass's colour plane, and k_accumulate adds the planes in pass order.
 #pragma once
+#include <type_traits>
+
 #include "kernels_pipeline.h"
 
 #ifndef RUN_RQ
@@ -49,6 +51,11 @@
 #ifndef RUN_TAIL_DIV
 #define RUN_TAIL_DIV 2                ///< tail: retire / shade once the finished lanes are 1/RUN_TAIL_DIV of the traversing ones
 #endif
+#ifndef RUN_THIN
+#define RUN_THIN 4                    ///< most lanes per ray in the tail (1: never leave wide mode; 2; 4). Once the cursor is dry and a wave is
+                                      ///< down to 32 (16) live paths and queries in flight, its rays are carried by pairs (quads) of lanes
+                                      ///< (device_scene.h "thin-wave modes"): a draining wave otherwise pays whole instructions for a few lanes
+#endif
 // Occupancy (gpurun_out/ab_occ.txt): 5 waves per SIMD need <= 96 VGPRs = 9 spilled registers and RUN_RQ 256 (7.5 KB of LDS): 64 passes as
 // one run 1.08 against 1.175 ms per pass, but one pass alone 2.37 against 2.21 and a 1/8 share with 20 passes unchanged; 6 waves (80 VGPRs,
 // 28 spills, 6-entry ring) lose everywhere. The shading code inside the kernel sets the register count; 4 waves it stays.
@@ -61,6 +68,21 @@
 // and the lane-rounds it spent traversing (active lanes summed over the rounds of the TRAVERSE loop / rounds)
 __device__ unsigned long long g_run_timeline[12 * 8192];
 __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-time per 25 us bucket
+#endif
+
+#ifdef GD_RUN_TIMELINE
+// one round of the TRAVERSE loop with `n` busy lanes (replicas included)
+#define GD_RUN_TL_ROUND(n)                                                                                                                     \
+    {                                                                                                                                          \
+        tl_lanes += (unsigned long long)(n); tl_rounds++; if (exhausted) tl_tail_rounds++;                                                     \
+        if (!exhausted) { tl_nready += n_ready; tl_nshade += n_shade; }                                                                        \
+        const unsigned long long now = wall_clock64();                                                                                         \
+        const unsigned bucket = (unsigned)min((now - (tl_zero ? tl_zero : tl_start)) / 2500ull, 127ull);                                       \
+        if (lane_id() == 0) { tl_hist[bucket] += (unsigned)(now - tl_prev) * (unsigned)(n); tl_hist[128 + bucket] += (unsigned)(now - tl_prev); } \
+        tl_prev = now;                                                                                                                         \
+    }
+#else
+#define GD_RUN_TL_ROUND(n)
 #endif
 
 namespace {
@@ -88,6 +110,15 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     bool first_chunk = true, exhausted = false;
     const uint32_t static_end = gridDim.x * BLOCK;  // the first chunk of every wave is static, the cursor starts behind them
 
+    // Thin-wave modes (tail only): M lanes per ray, rays at lanes [M q, M q + M) as identical replicas; `lead` = the first lane of
+    // every group, `sub` = this lane's index in its group, `below` then counts the groups before this lane's. Never entered by the
+    // counting variants (their counters are per lane) and by trees with irregular boxes (comparison-form box tests).
+    constexpr bool THIN_OK = RUN_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    uint32_t M = 1, sub = 0;                                   // M wave-uniform
+    unsigned long long lead = ~0ull;                           // wave-uniform
+    unsigned long long below_g = below;                        // the lanes before this lane's group
+    __shared__ uint32_t xfer[BLOCK];
+
     // per-lane query state
     uint32_t ent = SLOT_INVALID;            // the entry this lane works on (slot | flags), SLOT_INVALID: none
     F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0), rdiv = f3(1, 1, 1);
@@ -105,7 +136,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
         // ---- RETIRE: lanes whose query has finished --------------------------------------------------------------
         // (n_shade <= 63 here, see PRODUCE, so up to 64 appends fit the shade list)
         {
-            const bool done = ent != SLOT_INVALID && t.state == TRAV_DONE;
+            const bool done = ent != SLOT_INVALID && t.state == TRAV_DONE && (!THIN_OK || sub == 0);  // a ray's first replica retires it
             const uint32_t s = ent & RUN_SLOT;
             bool to_shade = false, joins = false, ended = false;
             if (done) {
@@ -136,9 +167,9 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             if (to_shade) shadeq[n_shade + (uint32_t)__popcll(m & below)] = ent & (RUN_SLOT | RUN_F_FRESH);
             n_shade += (uint32_t)__popcll(m);
             n_live -= (uint32_t)__popcll(__ballot(ended));
-            if (done) ent = SLOT_INVALID;
+            if (ent != SLOT_INVALID && t.state == TRAV_DONE) ent = SLOT_INVALID;
         }
-        const uint32_t need = (uint32_t)__popcll(__ballot(ent == SLOT_INVALID));
+        const uint32_t need = (uint32_t)__popcll(__ballot(ent == SLOT_INVALID) & lead);
 
         // ---- PRODUCE: shade full batches; generate new paths when the ready list cannot feed the idle lanes ------------
         // Bound on the lists. n_live counts the wave's live paths: +1 per generated path, -1 where a path is committed. A live
@@ -252,12 +283,61 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             n_live += (uint32_t)__popcll(m);
         }
 
+        // ---- THIN: the cursor is dry and few paths are left: fewer ray positions, more lanes per ray ---------------------------
+        if (THIN_OK && exhausted && M < (uint32_t)RUN_THIN) {
+            const unsigned long long flying = __ballot(ent != SLOT_INVALID) & lead;
+            const uint32_t most = max(n_live, (uint32_t)__popcll(flying));  // a path has up to two queries, the surplus waits in the ready list
+            const uint32_t to = most <= BLOCK / 4 && RUN_THIN >= 4 ? 4u : most <= BLOCK / 2 ? 2u : 1u;
+            if (to > M) {
+                // the q-th ray in flight moves to the lanes [to q, to q + to), and so does its stack column: a group's column is that
+                // of its first lane in every mode
+                if (ent != SLOT_INVALID && sub == 0) xfer[__popcll(flying & ((1ull << lane_id()) - 1))] = (uint32_t)lane_id();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const uint32_t q = (uint32_t)lane_id() / to;
+                const bool holds = q < (uint32_t)__popcll(flying);
+                const int src = holds ? (int)xfer[q] : lane_id();
+                ent = __shfl(ent, src, 64);
+                ro = f3(__shfl(ro.x, src, 64), __shfl(ro.y, src, 64), __shfl(ro.z, src, 64));
+                rd = f3(__shfl(rd.x, src, 64), __shfl(rd.y, src, 64), __shfl(rd.z, src, 64));
+                rdiv = f3(__shfl(rdiv.x, src, 64), __shfl(rdiv.y, src, 64), __shfl(rdiv.z, src, 64));
+                t.closest = __shfl(t.closest, src, 64); t.hit_prim = __shfl(t.hit_prim, src, 64); t.node = __shfl(t.node, src, 64);
+                t.entry = __shfl(t.entry, src, 64); t.state = __shfl(t.state, src, 64);
+                st.sp = __shfl(st.sp, src, 64); st.base = __shfl(st.base, src, 64);
+                if (!holds) { ent = SLOT_INVALID; t.state = TRAV_DONE; st.sp = 0; st.base = 0; }
+                // Columns, row by row: the loads of a row are one instruction of the whole wave and precede its stores, and a column that
+                // is some ray's destination may be another ray's source — but never in a different row.
+                const bool mover = holds && ((uint32_t)lane_id() % to) == 0 && src != lane_id();
+                for (uint32_t k = 0; k < GD_RING; k++) {
+                    const uint2 a = ring_a[k * BLOCK + (uint32_t)src];
+                    const float bb = ring_b[k * BLOCK + (uint32_t)src];
+                    if (mover) { ring_a[k * BLOCK + lane_id()] = a; ring_b[k * BLOCK + lane_id()] = bb; }
+                }
+                for (uint32_t k = 0; __ballot(mover && k < st.base) != 0; k++) {  // the spilled part (deep trees only)
+                    const bool mv = mover && k < st.base;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    const size_t row = (size_t)k * gridDim.x * BLOCK + (size_t)blockIdx.x * BLOCK;
+                    if (mv) v = spill[row + (uint32_t)src];
+                    if (mv) spill[row + lane_id()] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                {
+                    const uint32_t sp_keep = st.sp, base_keep = st.base;
+                    st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK, blockIdx.x, (uint32_t)lane_id() / to * to);
+                    st.sp = sp_keep; st.base = base_keep;
+                }
+                M = to;
+                sub = (uint32_t)lane_id() & (M - 1);
+                lead = M == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
+                below_g = (1ull << ((uint32_t)lane_id() & ~(M - 1))) - 1;
+            }
+        }
+
         // ---- REFILL: idle lanes take the oldest entries of the ready list ---------------------------------------------
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // rays / lists written by other lanes of this wave
-            const unsigned long long idle = __ballot(ent == SLOT_INVALID);
+            const unsigned long long idle = __ballot(ent == SLOT_INVALID) & lead;
             const uint32_t take = min((uint32_t)__popcll(idle), n_ready);
-            const uint32_t rank = (uint32_t)__popcll(idle & below);
+            const uint32_t rank = (uint32_t)__popcll(idle & below_g);  // the same for every replica of a group
             if (ent == SLOT_INVALID && rank < take) {
                 ent = ready[(r_head + rank) & (RUN_RQ - 1)];  // oldest first: with paths generated ahead, the youngest segments go first
                 ro = xyz(b.ray_o[ent & RUN_SLOT]);
@@ -277,6 +357,35 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #ifdef GD_RUN_TIMELINE
         { const unsigned long long now = wall_clock64(); if (exhausted) { tl_tail_other += now - tl_mark; tl_tail_trig++; } tl_mark = now; }
 #endif
+        if (THIN_OK && M > 1) {
+            // the same loop with M lanes per ray: ballots count groups (their first lanes), thresholds are in lanes
+            auto thin_rounds = [&](auto width) {
+                constexpr int W = decltype(width)::value;
+                for (;;) {
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    unsigned long long at_leaf = __ballot((t.state & 1) != 0) & lead;
+                    unsigned long long descending = __ballot(t.state == TRAV_DESCEND) & lead;
+                    const uint32_t waiting = (uint32_t)__popcll(at_leaf);
+                    if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
+                        if (t.state & 1) {
+                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+                            if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
+                        }
+                        descending = __ballot(t.state == TRAV_DESCEND) & lead;
+                        at_leaf = __ballot((t.state & 1) != 0) & lead;
+                    }
+                    const unsigned long long busy = descending | at_leaf;
+                    GD_RUN_TL_ROUND(W * (uint32_t)__popcll(busy))
+                    if (!busy) break;
+                    if ((uint32_t)BLOCK - W * (uint32_t)__popcll(busy) >= tune.refill_lanes) {
+                        const uint32_t finished = (uint32_t)__popcll(__ballot(ent != SLOT_INVALID && t.state == TRAV_DONE) & lead);
+                        if (n_ready || n_shade || finished * RUN_TAIL_DIV >= (uint32_t)__popcll(busy)) break;  // (the cursor is dry)
+                    }
+                }
+            };
+            if (M == 2) thin_rounds(std::integral_constant<int, 2>());
+            else thin_rounds(std::integral_constant<int, 4>());
+        } else
         for (;;) {
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
@@ -292,16 +401,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 at_leaf = __ballot((t.state & 1) != 0);
             }
             const unsigned long long busy = descending | at_leaf;
-#ifdef GD_RUN_TIMELINE
-            tl_lanes += (unsigned long long)__popcll(busy); tl_rounds++; if (exhausted) tl_tail_rounds++;
-            if (!exhausted) { tl_nready += n_ready; tl_nshade += n_shade; }
-            {
-                const unsigned long long now = wall_clock64();
-                const unsigned bucket = (unsigned)min((now - (tl_zero ? tl_zero : tl_start)) / 2500ull, 127ull);
-                if (lane_id() == 0) { tl_hist[bucket] += (unsigned)(now - tl_prev) * (unsigned)__popcll(busy); tl_hist[128 + bucket] += (unsigned)(now - tl_prev); }
-                tl_prev = now;
-            }
-#endif
+            GD_RUN_TL_ROUND((uint32_t)__popcll(busy))
             if (!busy) break;
             if (64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) {
                 // worth a round of RETIRE / PRODUCE / REFILL if that can put idle lanes back to work: a finished lane

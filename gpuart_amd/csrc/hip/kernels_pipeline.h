@@ -83,15 +83,18 @@ GD_FN bool slot_pixel(const Frame &f, uint32_t slot, uint32_t &lx, uint32_t &ly)
 
 /// The traversal stack of this lane: its column of the wave's LDS ring, its column of the launch's spill area
 /// (`wave` of `total_lanes / 64` waves).
-GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes, uint32_t wave) {
+GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes, uint32_t wave, uint32_t column) {
     TravStack st;
-    st.ring_a = ring_a + lane_id();
-    st.ring_b = ring_b + lane_id();
+    st.ring_a = ring_a + column;
+    st.ring_b = ring_b + column;
     st.ring_stride = BLOCK;
-    st.spill = spill + (size_t)wave * BLOCK + lane_id();
+    st.spill = spill + (size_t)wave * BLOCK + column;
     st.spill_stride = total_lanes;
     st.reset();
     return st;
+}
+GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes, uint32_t wave) {
+    return make_stack(ring_a, ring_b, spill, total_lanes, wave, (uint32_t)lane_id());
 }
 GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes) {
     return make_stack(ring_a, ring_b, spill, total_lanes, blockIdx.x);
