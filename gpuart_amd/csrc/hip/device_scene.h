@@ -453,11 +453,8 @@ GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
 
 /// Returns to the nearest pending upper child that is still worth visiting (or finishes).
 template <bool COUNT>
-GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true, unsigned long long *pops = nullptr) {
+GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true) {
     for (;;) {
-#ifdef GD_RUN_TIMELINE
-        if (pops) ++*pops;
-#endif
         if (st.sp == 0) { t.state = TRAV_DONE; return; }
         StackEntry e = st.pop(writer);
         if (e.pe > t.closest) continue;   // the reference's parent re-test fails: skip the upper child
@@ -584,16 +581,6 @@ GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st,
 // Everything else (stack, descent, pops, the generic leaf loops) runs replicated and unchanged, so the walk visits the same
 // nodes in the same order and returns the same bits. Fast-form boxes only (trees with irregular boxes stay in wide mode).
 
-#ifdef GD_RUN_TIMELINE
-/// diagnostic build (tools/run_timeline.py): shader-clock cycles of the parts of a thin step, summed per wave
-struct ThinProbe { unsigned long long fetch, test, push, walk, pops, leaf_fetch, leaf_test, leaf_walk; };
-#define GD_PROBE_CLOCK(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
-#define GD_PROBE_ADD(field, a, b) if (pr) pr->field += (b) - (a);
-#else
-struct ThinProbe;
-#define GD_PROBE_CLOCK(var)
-#define GD_PROBE_ADD(field, a, b)
-#endif
 /// quad_perm controls of v_mov_b32_dpp: lane i of every quad reads lane p_i of the same quad.
 #define GD_QUAD_PERM(p0, p1, p2, p3) ((p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6))
 template <int CTRL>
@@ -603,24 +590,15 @@ GD_FN float quad_f(float v) { return __uint_as_float(quad_u<CTRL>(__float_as_uin
 
 /// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them). Precondition: DESCEND.
 template <int M>
-GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, ThinProbe *pr = nullptr) {
+GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub) {
     static_assert(M == 2 || M == 4, "two or four lanes per ray");
     const float4 *rec = sc.recs + 4 * (size_t)t.node;
     const float INF = __builtin_inff();
     float e;  // this lane's box: entry parameter, GD_ENTRY_MISS when not hit
     uint32_t ref_lo, ref_hi;
-    GD_PROBE_CLOCK(c0)
-#ifdef GD_RUN_TIMELINE
-    const unsigned long long fetch_before = pr ? pr->fetch : 0;
-#endif
     if (M == 4) {
         float4 mine = rec[sub];  // 0: lo.min | lo ref, 1: lo.max | hi ref, 2: hi.min, 3: hi.max
         asm volatile("" : "+v"(mine.w));  // keep the ref in the 16-byte load (see trav_step_box)
-#ifdef GD_RUN_TIMELINE
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mine.x), "+v"(mine.y), "+v"(mine.z), "+v"(mine.w));
-        GD_PROBE_CLOCK(c1)
-        GD_PROBE_ADD(fetch, c0, c1)
-#endif
         const F3 other = f3(quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.x), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.y), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.z));
         const bool inside = within(ro.x, mine.x, other.x) & within(ro.y, mine.y, other.y) & within(ro.z, mine.z, other.z);
         const float cx = face_candidate((mine.x - ro.x) * rdiv.x, ro.y, rd.y, mine.y, other.y, ro.z, rd.z, mine.z, other.z);
@@ -641,56 +619,33 @@ GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, T
         ref_lo = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmin.w));
         ref_hi = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmax.w));
     }
-    float el = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(e) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(e);
+    const float el = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(e) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(e);
     const float eh = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(e) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(e);
     const bool writer = sub == 0;
-#ifdef GD_RUN_TIMELINE
-    asm volatile("" : "+v"(el));
-    GD_PROBE_CLOCK(c2)
-    if (M == 4) GD_PROBE_ADD(test, c0, c2)
-    if (M == 4 && pr) pr->test -= pr->fetch - fetch_before;
-#endif
     if (eh != GD_ENTRY_MISS) {
         StackEntry s;
         s.ref = ref_hi; s.pe = t.entry; s.he = eh;
         st.push(s, writer);
     }
-    GD_PROBE_CLOCK(c3)
-    GD_PROBE_ADD(push, c2, c3)
     if (el != GD_ENTRY_MISS && !(el > t.closest)) {
         trav_enter(t, ref_lo, el);
-    } else {
-#ifdef GD_RUN_TIMELINE
-        trav_pop<false>(t, st, nullptr, writer, pr ? &pr->pops : nullptr);
-#else
-        trav_pop<false>(t, st, nullptr, writer);
-#endif
+        return;
     }
-#ifdef GD_RUN_TIMELINE
-    asm volatile("" : "+v"(t.state));
-    GD_PROBE_CLOCK(c4)
-    GD_PROBE_ADD(walk, c3, c4)
-#endif
+    trav_pop<false>(t, st, nullptr, writer);
 }
 
 /// The pending leaf of a ray carried by M replicas, then the pop. A leaf of one or two triangles is split between the halves
 /// of the group; every other leaf runs replicated through the code of `trav_step_leaf`.
 template <int M, int TYPES>
-GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub, ThinProbe *pr = nullptr) {
+GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub) {
     const bool writer = sub == 0;
-    GD_PROBE_CLOCK(c0)
     constexpr bool SMALL_PATH = (TYPES & 0xF) != ((1 << P_DISC) | (1 << P_TRIANGLE));
     const Ray r{ro, rd};
     if (t.state & 8) {
         const bool two = t.state == TRAV_LEAF_TRIS;
         const bool second = (M == 4 ? (sub >> 1) : sub) != 0;
         const float4 *pa = sc.prims + 3 * (size_t)t.node + ((second && two) ? 3 : 0);
-        float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
-#ifdef GD_RUN_TIMELINE
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x));
-        GD_PROBE_CLOCK(c1)
-        GD_PROBE_ADD(leaf_fetch, c0, c1)
-#endif
+        const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
         const float tt = triangle_t(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, a0, a1, a2);
         const float ta = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(tt) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(tt);
         float tb = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(tt) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(tt);
@@ -702,17 +657,7 @@ GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack
     } else {
         leaf_test<false, false, TYPES>(sc, r, t.node, t.closest, t.hit_prim, nullptr);
     }
-#ifdef GD_RUN_TIMELINE
-    asm volatile("" : "+v"(t.closest));
-    GD_PROBE_CLOCK(c2)
-    GD_PROBE_ADD(leaf_test, c0, c2)
-    trav_pop<false>(t, st, nullptr, writer, pr ? &pr->pops : nullptr);
-    asm volatile("" : "+v"(t.state));
-    GD_PROBE_CLOCK(c3)
-    GD_PROBE_ADD(leaf_walk, c2, c3)
-#else
     trav_pop<false>(t, st, nullptr, writer);
-#endif
 }
 
 /// Runs one query to completion (megakernels and test hooks).

@@ -66,7 +66,7 @@
 #ifdef GD_RUN_TIMELINE
 // diagnostic build (tools/run_timeline.py): per wave, the 100 MHz clock at its start, when the cursor ran dry, at its end,
 // and the lane-rounds it spent traversing (active lanes summed over the rounds of the TRAVERSE loop / rounds)
-__device__ unsigned long long g_run_timeline[32 * 8192];
+__device__ unsigned long long g_run_timeline[16 * 8192];
 __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-time per 25 us bucket
 #endif
 
@@ -129,8 +129,6 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start, tl_nready = 0, tl_nshade = 0;
     unsigned long long tl_tail_trav = 0, tl_tail_other = 0, tl_tail_rounds = 0, tl_tail_trig = 0, tl_mark = tl_start;
     unsigned long long tl_m2 = 0, tl_m4 = 0, tl_r2 = 0, tl_r4 = 0;  // when the wave went to pairs / quads, rounds in either mode
-    ThinProbe tpr = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tp_wait_box = 0, tp_box = 0, tp_wait_leaf = 0, tp_leaf = 0, tp_nbox = 0, tp_nleaf = 0, tp_loop = 0;  // shader-clock cycles of the quad rounds
     __shared__ unsigned tl_hist[2 * 128];
     tl_hist[lane_id()] = 0; tl_hist[64 + lane_id()] = 0; tl_hist[128 + lane_id()] = 0; tl_hist[192 + lane_id()] = 0;
     const unsigned long long tl_zero = g_run_hist[2 * 128 - 1];  // the host stores the launch's reference clock there (0: use own start)
@@ -293,42 +291,9 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             const uint32_t most = max(n_live, (uint32_t)__popcll(flying));  // a path has up to two queries, the surplus waits in the ready list
             const uint32_t to = most <= BLOCK / 4 && RUN_THIN >= 4 ? 4u : most <= BLOCK / 2 ? 2u : 1u;
             if (to > M) {
-                // the q-th ray in flight moves to the lanes [to q, to q + to), and so does its stack column: a group's column is that
-                // of its first lane in every mode
-                if (ent != SLOT_INVALID && sub == 0) xfer[__popcll(flying & ((1ull << lane_id()) - 1))] = (uint32_t)lane_id();
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                const uint32_t q = (uint32_t)lane_id() / to;
-                const bool holds = q < (uint32_t)__popcll(flying);
-                const int src = holds ? (int)xfer[q] : lane_id();
-                ent = __shfl(ent, src, 64);
-                ro = f3(__shfl(ro.x, src, 64), __shfl(ro.y, src, 64), __shfl(ro.z, src, 64));
-                rd = f3(__shfl(rd.x, src, 64), __shfl(rd.y, src, 64), __shfl(rd.z, src, 64));
-                rdiv = f3(__shfl(rdiv.x, src, 64), __shfl(rdiv.y, src, 64), __shfl(rdiv.z, src, 64));
-                t.closest = __shfl(t.closest, src, 64); t.hit_prim = __shfl(t.hit_prim, src, 64); t.node = __shfl(t.node, src, 64);
-                t.entry = __shfl(t.entry, src, 64); t.state = __shfl(t.state, src, 64);
-                st.sp = __shfl(st.sp, src, 64); st.base = __shfl(st.base, src, 64);
-                if (!holds) { ent = SLOT_INVALID; t.state = TRAV_DONE; st.sp = 0; st.base = 0; }
-                // Columns, row by row: the loads of a row are one instruction of the whole wave and precede its stores, and a column that
-                // is some ray's destination may be another ray's source — but never in a different row.
-                const bool mover = holds && ((uint32_t)lane_id() % to) == 0 && src != lane_id();
-                for (uint32_t k = 0; k < GD_RING; k++) {
-                    const uint2 a = ring_a[k * BLOCK + (uint32_t)src];
-                    const float bb = ring_b[k * BLOCK + (uint32_t)src];
-                    if (mover) { ring_a[k * BLOCK + lane_id()] = a; ring_b[k * BLOCK + lane_id()] = bb; }
-                }
-                for (uint32_t k = 0; __ballot(mover && k < st.base) != 0; k++) {  // the spilled part (deep trees only)
-                    const bool mv = mover && k < st.base;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    const size_t row = (size_t)k * gridDim.x * BLOCK + (size_t)blockIdx.x * BLOCK;
-                    if (mv) v = spill[row + (uint32_t)src];
-                    if (mv) spill[row + lane_id()] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                {
-                    const uint32_t sp_keep = st.sp, base_keep = st.base;
-                    st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK, blockIdx.x, (uint32_t)lane_id() / to * to);
-                    st.sp = sp_keep; st.base = base_keep;
-                }
+                uint32_t unused = 0;
+                thin_regroup(to, flying, xfer, ring_a, ring_b, spill, ent, unused, ro, rd, rdiv, t, st);
+                if ((uint32_t)lane_id() / to >= (uint32_t)__popcll(flying)) ent = SLOT_INVALID;  // the groups beyond the rays in flight are idle
                 M = to;
 #ifdef GD_RUN_TIMELINE
                 if (M == 2) tl_m2 = wall_clock64(); else { tl_m4 = wall_clock64(); }
@@ -368,42 +333,23 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             // the same loop with M lanes per ray: ballots count groups (their first lanes), thresholds are in lanes
             auto thin_rounds = [&](auto width) {
                 constexpr int W = decltype(width)::value;
+                constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
-#ifdef GD_RUN_TIMELINE
-                    const unsigned long long pc0 = __builtin_amdgcn_s_memtime();
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub, W == 4 ? &tpr : nullptr);
-                    if (W == 4) { tp_nbox++; tp_box += __builtin_amdgcn_s_memtime() - pc0; }
-#else
                     if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
-#endif
-                    unsigned long long at_leaf = __ballot((t.state & 1) != 0) & lead;
-                    unsigned long long descending = __ballot(t.state == TRAV_DESCEND) & lead;
+                    unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
+                    unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
-                    if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
-#ifdef GD_RUN_TIMELINE
-                        const unsigned long long pl0 = __builtin_amdgcn_s_memtime();
-                        if (t.state & 1) {
-                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub, W == 4 ? &tpr : nullptr);
-                            if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
-                        }
-                        if (W == 4) { tp_nleaf++; tp_leaf += __builtin_amdgcn_s_memtime() - pl0; }
-#else
+                    if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
                         if (t.state & 1) {
                             trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
                             if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                         }
-#endif
-                        descending = __ballot(t.state == TRAV_DESCEND) & lead;
-                        at_leaf = __ballot((t.state & 1) != 0) & lead;
+                        busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     }
-                    const unsigned long long busy = descending | at_leaf;
                     GD_RUN_TL_ROUND((uint32_t)__popcll(busy))
-#ifdef GD_RUN_TIMELINE
-                    if (W == 4) tp_loop += __builtin_amdgcn_s_memtime() - pc0;
-#endif
                     if (!busy) break;
                     if ((uint32_t)BLOCK - W * (uint32_t)__popcll(busy) >= tune.refill_lanes) {
-                        const uint32_t finished = (uint32_t)__popcll(__ballot(ent != SLOT_INVALID && t.state == TRAV_DONE) & lead);
+                        const uint32_t finished = (uint32_t)__popcll(__ballot(ent != SLOT_INVALID && t.state == TRAV_DONE) & LEAD);
                         if (n_ready || n_shade || finished * RUN_TAIL_DIV >= (uint32_t)__popcll(busy)) break;  // (the cursor is dry)
                     }
                 }
@@ -444,10 +390,8 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     if (COUNT) flush_counters(wc, segments, gcounters);
 #ifdef GD_RUN_TIMELINE
     if (lane_id() == 0 && blockIdx.x < 8192) {
-        unsigned long long *o = g_run_timeline + 32 * blockIdx.x;
+        unsigned long long *o = g_run_timeline + 16 * blockIdx.x;
         o[12] = tl_m2; o[13] = tl_m4; o[14] = tl_r2; o[15] = tl_r4;
-        o[16] = tp_wait_box; o[17] = tp_box; o[18] = tp_wait_leaf; o[19] = tp_leaf; o[20] = tp_nbox; o[21] = tp_nleaf; o[22] = tp_loop; o[23] = 0;
-        o[24] = tpr.fetch; o[25] = tpr.test; o[26] = tpr.push; o[27] = tpr.walk; o[28] = tpr.pops; o[29] = tpr.leaf_fetch; o[30] = tpr.leaf_test; o[31] = tpr.leaf_walk;
         o[6] = tl_nready; o[7] = tl_nshade; o[8] = tl_tail_trav; o[9] = tl_tail_other; o[10] = tl_tail_rounds; o[11] = tl_tail_trig;
         o[0] = tl_start; o[1] = tl_dry; o[2] = wall_clock64(); o[3] = tl_lanes; o[4] = tl_rounds;
         for (int k = 0; k < 256; k++) if (tl_hist[k]) atomicAdd(&g_run_hist[k], (unsigned long long)tl_hist[k]);

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_shade.h"
 #include "gpuart_hip.h"
 
@@ -100,6 +102,46 @@ GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t 
     return make_stack(ring_a, ring_b, spill, total_lanes, blockIdx.x);
 }
 
+/// Thin-wave modes (device_scene.h): regroups a wave's rays for `to` lanes per ray. The q-th ray in flight (`flying`: the first
+/// lanes of the groups that hold one) moves to the lanes [to q, to q + to) as identical replicas — the two tags, the ray, the
+/// traversal state — and so does its stack column (LDS ring and global spill): a group's column is that of its first lane in
+/// every mode. Groups beyond the rays in flight come out idle (state DONE, empty stack; their tags are the caller's to reset).
+/// `xfer`: 64 words of LDS scratch.
+GD_FN void thin_regroup(uint32_t to, unsigned long long flying, uint32_t *xfer, uint2 *ring_a, float *ring_b, uint4 *spill,
+                        uint32_t &tag0, uint32_t &tag1, F3 &ro, F3 &rd, F3 &rdiv, Trav &t, TravStack &st) {
+    if ((flying >> lane_id()) & 1ull) xfer[__popcll(flying & ((1ull << lane_id()) - 1))] = (uint32_t)lane_id();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const uint32_t q = (uint32_t)lane_id() / to;
+    const bool holds = q < (uint32_t)__popcll(flying);
+    const int src = holds ? (int)xfer[q] : lane_id();
+    tag0 = __shfl(tag0, src, 64); tag1 = __shfl(tag1, src, 64);
+    ro = f3(__shfl(ro.x, src, 64), __shfl(ro.y, src, 64), __shfl(ro.z, src, 64));
+    rd = f3(__shfl(rd.x, src, 64), __shfl(rd.y, src, 64), __shfl(rd.z, src, 64));
+    rdiv = f3(__shfl(rdiv.x, src, 64), __shfl(rdiv.y, src, 64), __shfl(rdiv.z, src, 64));
+    t.closest = __shfl(t.closest, src, 64); t.hit_prim = __shfl(t.hit_prim, src, 64); t.node = __shfl(t.node, src, 64);
+    t.entry = __shfl(t.entry, src, 64); t.state = __shfl(t.state, src, 64);
+    uint32_t sp = __shfl(st.sp, src, 64), base = __shfl(st.base, src, 64);
+    if (!holds) { t.state = TRAV_DONE; sp = 0; base = 0; }
+    // Columns, row by row: the loads of a row are one instruction of the whole wave and precede its stores, and a column that
+    // is some ray's destination may be another ray's source — but never in a different row.
+    const bool mover = holds && ((uint32_t)lane_id() % to) == 0 && src != lane_id();
+    for (uint32_t k = 0; k < GD_RING; k++) {
+        const uint2 a = ring_a[k * BLOCK + (uint32_t)src];
+        const float bb = ring_b[k * BLOCK + (uint32_t)src];
+        if (mover) { ring_a[k * BLOCK + lane_id()] = a; ring_b[k * BLOCK + lane_id()] = bb; }
+    }
+    for (uint32_t k = 0; __ballot(mover && k < base) != 0; k++) {  // the spilled part (deep trees only)
+        const bool mv = mover && k < base;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const size_t row = (size_t)k * gridDim.x * BLOCK + (size_t)blockIdx.x * BLOCK;
+        if (mv) v = spill[row + (uint32_t)src];
+        if (mv) spill[row + lane_id()] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK, blockIdx.x, (uint32_t)lane_id() / to * to);
+    st.sp = sp; st.base = base;
+}
+
 /// Wave-aggregated append: lanes with `pred` get consecutive positions of `queue` (one atomic per wave).
 GD_FN void queue_push(uint32_t *queue, uint32_t *counter, bool pred, uint32_t value) {
     unsigned long long m = __ballot(pred);
@@ -181,6 +223,9 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
 #ifndef GD_TRACE_WAVES
 #define GD_TRACE_WAVES 5  // waves per SIMD the register allocation must allow (<= 96 VGPRs)
 #endif
+#ifndef GD_TRACE_THIN
+#define GD_TRACE_THIN 4  // most lanes per ray in a draining wave (1: never leave wide mode)
+#endif
 #ifndef GD_TRACE_WAVES_LEAN
 #define GD_TRACE_WAVES_LEAN 6  // the kernels without cone / sphere code fit 6 waves per SIMD (<= 80 VGPRs)
 #endif
@@ -192,6 +237,10 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     __shared__ float ring_b[GD_RING * BLOCK];
     const uint32_t wave_id = blockIdx.x, n_waves = gridDim.x;  // one wavefront per workgroup
     TravStack st = make_stack(ring_a, ring_b, spill, n_waves * BLOCK, wave_id);
+    // Thin-wave modes (device_scene.h): once the queue is empty and the wave is down to 32 (16) rays, pairs (quads) of lanes carry
+    // them. Not in the counting variant (its counters are per lane) nor for trees with irregular boxes.
+    constexpr bool THIN_OK = GD_TRACE_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    uint32_t M = 1, sub = 0;  // M wave-uniform
     const uint32_t *queue_c = b.queue[seg_c & 1];
     const uint32_t n_c = seg_c >= 0 ? b.counters[4 * seg_c] : 0u;
     const uint32_t n = n_c + (seg_s >= 0 ? b.counters[4 * seg_s + 2] : 0u);
@@ -242,10 +291,50 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             idle = __ballot(slot == SLOT_INVALID);
             if (take == want) break;
         }
-        if (__ballot(slot != SLOT_INVALID) == 0) {
+        const unsigned long long flying = __ballot(slot != SLOT_INVALID && sub == 0);
+        if (flying == 0) {
             if (exhausted) break;
             continue;
         }
+        if (THIN_OK && exhausted && M < (uint32_t)GD_TRACE_THIN) {
+            const uint32_t left = (uint32_t)__popcll(flying);
+            const uint32_t to = left <= BLOCK / 4 && GD_TRACE_THIN >= 4 ? 4u : left <= BLOCK / 2 ? 2u : 1u;
+            if (to > M) {
+                uint32_t sh = shadow ? 1u : 0u;
+                // (the stack ring doubles as the scratch of the move: row 0 is copied first, and the table is read before that)
+                __shared__ uint32_t xfer[BLOCK];
+                thin_regroup(to, flying, xfer, ring_a, ring_b, spill, slot, sh, ro, rd, rdiv, t, st);
+                shadow = sh != 0;
+                if ((uint32_t)lane_id() / to >= left) slot = SLOT_INVALID;
+                M = to;
+                sub = (uint32_t)lane_id() & (M - 1);
+            }
+        }
+        if (THIN_OK && M > 1) {
+            // the loop below with M lanes per ray (every ray is in flight until it is done: the queue is empty)
+            auto thin_rounds = [&](auto width) {
+                constexpr int W = decltype(width)::value;
+                constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
+                for (;;) {
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
+                    unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
+                    const uint32_t waiting = (uint32_t)__popcll(at_leaf);
+                    if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
+                        if (t.state & 1) {
+                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+                            if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
+                        }
+                        busy = __ballot(t.state != TRAV_DONE) & LEAD;
+                    }
+                    if (!busy) break;
+                    // a wave may move to quads once it is down to 16 rays
+                    if (W == 2 && GD_TRACE_THIN >= 4 && (uint32_t)__popcll(busy) <= BLOCK / 4) break;
+                }
+            };
+            if (M == 2) thin_rounds(std::integral_constant<int, 2>());
+            else thin_rounds(std::integral_constant<int, 4>());
+        } else
         // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
@@ -266,9 +355,11 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             unsigned long long busy = descending | at_leaf;
             if (!busy) break;
             if (!exhausted && 64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
+            // a draining wave may move to pairs / quads once it is down to 32 rays
+            if (THIN_OK && exhausted && (uint32_t)__popcll(busy) <= BLOCK / 2) break;
         }
-        // ---- retire finished rays
-        if (slot != SLOT_INVALID && t.state == TRAV_DONE) {
+        // ---- retire finished rays (a ray's first replica retires it)
+        if (slot != SLOT_INVALID && t.state == TRAV_DONE && (!THIN_OK || sub == 0)) {
             if (!shadow) {
                 b.hit[slot] = make_uint2(__float_as_uint(t.closest), t.hit_prim);
             } else {
@@ -278,8 +369,8 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                 if (__float_as_uint(term.w) & 1u) path_commit(f, b, accum, slot, j, npaths, pathColor);
                 else b.pc[slot] = make_float4(pathColor.x, pathColor.y, pathColor.z, 0);
             }
-            slot = SLOT_INVALID;
         }
+        if (slot != SLOT_INVALID && t.state == TRAV_DONE) slot = SLOT_INVALID;
     }
     if (COUNT) flush_counters(wc, 0, gcounters);
 }

@@ -30,7 +30,7 @@ for it in range(3):
         r.path_tracing_pass()
     r.finish()
 n = 4096
-buf = np.zeros((n, 32), np.uint64)
+buf = np.zeros((n, 16), np.uint64)
 L.gpuart_hip_debug_run_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = L.gpuart_hip_debug_run_timeline(r.backend.ctx, buf.ctypes.data_as(C.c_void_p), n)
 assert rc == 0, rc
@@ -48,12 +48,6 @@ for name, col, rc in (("pairs", 12, 14), ("quads", 13, 15)):
     sel = buf[:, col] > 0
     if sel.any():
         print("to %s     " % name, q(us(buf[sel, col])), " (%d waves; rounds in that mode, median %d)" % (int(sel.sum()), int(np.median(buf[sel, rc]))))
-f = lambda k: buf[:, k].astype(np.float64).sum()
-if f(20) > 0:
-    nb, nl = f(20), max(1.0, f(21))
-    print("quad rounds, all waves (shader-clock cycles; every clock read costs ~100 itself): %d rounds of %.0f cycles" % (f(15), f(22) / max(1, f(15))))
-    print("  box step  x %d: %.0f = record fetch %.0f + face tests %.0f + push %.0f + enter / pop %.0f" % (nb, f(17) / nb, f(24) / nb, f(25) / nb, f(26) / nb, f(27) / nb))
-    print("  leaf step x %d: %.0f = triangle fetch %.0f + tests %.0f (incl. fetch) + pop %.0f;  pop iterations per step (box + leaf): %.2f" % (nl, f(19) / nl, f(29) / nl, f(30) / nl, f(31) / nl, f(28) / (nb + nl)))
 print("ready / shade list lengths summed over the rounds before the cursor ran dry / all rounds (lower bound of the mean): %.1f / %.1f" % (buf[:, 6].sum() / buf[:, 4].sum(), buf[:, 7].sum() / buf[:, 4].sum()))
 tt, to, tr, tg = [buf[:, k].astype(np.float64) for k in (8, 9, 10, 11)]
 print("after the cursor ran dry, per wave (medians): %.0f us in traversal rounds (%d rounds, %.2f us each), %.0f us in retire / shade / refill (%d times, %.2f us each)" % (
