@@ -204,7 +204,11 @@ def comm_unique_id():
 
 
 class HipError(RuntimeError):
-    pass
+    """A gpuart_hip_* call returned an error; `code` is the library's (GPUART_HIP_ERR_*: -4 a bounded wait ran out)."""
+    code = None
+
+
+ERR_TIMEOUT = -4
 
 
 class Backend:
@@ -223,7 +227,9 @@ class Backend:
 
     def _chk(self, rc):
         if rc != 0:
-            raise HipError("gpuart_hip error %d: %s" % (rc, self.L.gpuart_hip_last_error().decode()))
+            e = HipError("gpuart_hip error %d: %s" % (rc, self.L.gpuart_hip_last_error().decode()))
+            e.code = rc
+            raise e
 
     def close(self):
         if self.owned and self.ctx:
@@ -308,8 +314,18 @@ class Backend:
         """Collective: assembles every rank's share on `root` (full_frame_device_ptr: W*H*4 floats on the root, else 0)."""
         self._chk(self.L.gpuart_hip_gather(self.ctx, which, C.c_float(divide_by), root, C.c_void_p(full_frame_device_ptr or None)))
 
+    def comm_info(self):
+        """(ranks, own rank) as the communicator itself reports them (ncclCommCount, ncclCommUserRank)."""
+        n, me = C.c_int(0), C.c_int(0)
+        self._chk(self.L.gpuart_hip_comm_info(self.ctx, C.byref(n), C.byref(me)))
+        return n.value, me.value
+
     def finish(self):
         self._chk(self.L.gpuart_hip_finish(self.ctx))
+
+    def wait(self, timeout_ms):
+        """finish() with a bound: HipError with code ERR_TIMEOUT if the context's work is not complete after timeout_ms."""
+        self._chk(self.L.gpuart_hip_wait(self.ctx, C.c_uint32(int(timeout_ms))))
 
     MODE_WAVEFRONT, MODE_REFERENCE_WORK, MODE_MEGAKERNEL = 0, 1, 2
 

@@ -34,6 +34,8 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -57,6 +59,8 @@ Rccl *rccl() {
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     return &r;

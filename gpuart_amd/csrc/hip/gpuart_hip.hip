@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +22,7 @@
 #include "kernels_test.h"
 #include "converter.h"
 #include "gather.h"
+#include "run_planner.h"
 
 // =================================================================================================
 // Host side: context, upload, launches
@@ -88,6 +91,7 @@ struct gpuart_hip_ctx {
     hipStream_t stream = nullptr;  ///< primary stream: accumulation (in pass order), direct lighting, copies, test hooks
     Frame frame{};
     bool have_camera = false, have_scene = false;
+    bool empty_share = false;      ///< gpuart_hip_set_share with th == 0: nothing to render, still a member of the gather
     float4 *d_recs = nullptr, *d_prims = nullptr;
     uint32_t *d_cursor = nullptr;  ///< pixel cursor of k_direct_persistent
     uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow for kernels on the primary stream
@@ -100,17 +104,7 @@ struct gpuart_hip_ctx {
     uint32_t shade_waves = 4096;   ///< grid of the streaming kernels (k_gen, k_shade): latency-bound, so more waves than k_trace
     uint32_t run_waves = 5120;     ///< grid of k_run: fills every SIMD by itself (5 waves per SIMD)
     TraceTuning tune{128, 16, 16, 3};
-    uint32_t n_slots = 0;          ///< path slots of the tile (8x8-tile padded)
-    uint32_t max_batch = 1;        ///< most passes one run of the pipeline may hold (batch_paths / tile slots, <= MAX_BATCH)
-    uint32_t batch_limit = MAX_BATCH;  ///< user cap (GPUART_HIP_MAX_BATCH)
-    size_t batch_paths = (size_t)16 << 20;  ///< passes are batched while one pipeline run stays within this many paths
-    size_t min_run_paths = (size_t)2 << 20;  ///< a pipeline run is not made smaller than this many paths
-    double plan_run_factor = 0.75; ///< run length = this x sqrt(planned work), in units of 2M paths (plan_runs)
     bool lean_kernels = true;      ///< use the BVH-query kernels specialised for the primitive types present
-    uint32_t planned_passes = 0;   ///< gpuart_hip_pt_plan hint (0: unknown)
-    size_t run_passes = 1;         ///< passes per pipeline run (see plan_runs)
-    uint32_t lanes_in_use = 1;     ///< pass lanes cycled through (all of them unless their path state would exceed lane_budget)
-    size_t lane_budget = (size_t)16 << 30;  ///< bytes of wavefront path state over all lanes
     // passes requested through gpuart_hip_pt_pass but not launched yet (same params, one seed each)
     std::vector<float4> pend_seeds;
     gpuart_params pend_params{};
@@ -123,12 +117,11 @@ struct gpuart_hip_ctx {
     uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box (converter.h): box tests take the comparison form
     uint32_t max_depth = 0;
     float4 *d_direct = nullptr, *d_accum = nullptr;
-    size_t tile_pixels = 0;
     unsigned long long *d_counters = nullptr;
-    int mode = 0;  ///< gpuart_hip_set_mode: 0 fast (launch pipeline, or k_run for a small sequence), 1 reference work +
-                   ///< counters (k_run), 2 megakernel, 3 launch pipeline always, 4 fast with counters of the executed work
-                   ///< (k_run), 5 k_run always
-    size_t small_paths = (size_t)4 << 20;  ///< a pass sequence of at most this many paths goes through k_run in mode 0
+    /// Tile size, run lengths, lanes in use, execution mode (gpuart_hip_set_mode: 0 fast — launch pipeline, or k_run for a small
+    /// sequence —, 1 reference work + counters (k_run), 2 megakernel, 3 launch pipeline always, 4 fast with counters of the
+    /// executed work (k_run), 5 k_run always) and the passes collected but not launched: run_planner.h
+    RunPlanner plan;
     std::vector<TimedLaunch> pending, free_events;
     double timed_ms[2] = {0, 0};
     uint64_t timed_launches[2] = {0, 0};
@@ -141,7 +134,8 @@ struct gpuart_hip_ctx {
     bool comm_owned = false;          ///< made by gpuart_hip_comm_init / _init_all (destroyed with the context)
     float4 *d_send = nullptr, *d_stage = nullptr;
     size_t send_pixels = 0, stage_pixels = 0;
-    gpuart_tile_geom *d_geoms = nullptr;  ///< [1 + nranks]: own geometry, then everybody's (ncclAllGather)
+    void *d_hello = nullptr;          ///< [1 + nranks] GatherHello: own share + status, then everybody's (ncclAllGather)
+    uint32_t gather_timeout_ms = 60000;  ///< GPUART_HIP_GATHER_TIMEOUT_MS: bound on the host-side wait for the peers (0: none)
 };
 
 namespace {
@@ -159,75 +153,48 @@ int drain(gpuart_hip_ctx *c) {
 extern "C" int gpuart_hip_flush(gpuart_hip_ctx *c);
 namespace {
 
-/// Passes per pipeline run. Runs should be long (a persistent launch that takes many rays per lane wastes less of its
-/// instructions on draining its last rays) and numerous (their kernels fill each other's tails, and more runs than lanes
-/// keeps the lanes out of step). For a planned sequence of u units of work (1 unit = 2M paths, one 1080p pass) the best
-/// run length measured on cfg3 was 1, 1, 2-3, 3-4, 6 units for u = 2, 4, 8, 20, 64 — about 0.75 sqrt(u); never below
-/// `min_run_paths`, never above max_batch (16M paths). Without a plan: 8M paths.
-void plan_runs(gpuart_hip_ctx *c) {
-    if (!c->n_slots) { c->run_passes = 1; return; }
-    const double unit = (double)((size_t)2 << 20);
-    const size_t min_run = std::max<size_t>(1, c->min_run_paths / c->n_slots);
-    size_t want;
-    if (c->planned_passes && (c->mode == 0 || c->mode == 5) && c->planned_passes <= c->max_batch &&
-        (c->small_paths ? c->planned_passes == 1 || (size_t)c->planned_passes * c->n_slots <= c->small_paths : c->mode == 5)) {
-        want = c->planned_passes;  // a small sequence is ONE run of the persistent kernel (uses_run_kernel)
-    } else if (c->planned_passes) {
-        const double u = (double)c->planned_passes * c->n_slots / unit;
-        want = (size_t)(c->plan_run_factor * std::sqrt(u) * unit / c->n_slots);
-    } else {
-        want = std::max<size_t>(1, ((size_t)8 << 20) / c->n_slots);
-    }
-    c->run_passes = std::min<size_t>(c->max_batch, std::max(min_run, want));
-}
-
 int realloc_tile(gpuart_hip_ctx *c) {
     int r = gpuart_hip_flush(c);
     if (r) return r;
     if ((r = drain(c))) return r;
+    c->empty_share = false;
     if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; }
     if (c->d_accum) { (void)hipFree(c->d_accum); c->d_accum = nullptr; }
-    c->tile_pixels = (size_t)c->frame.tw * c->frame.th;
-    if (!c->tile_pixels) return 0;
-    HIP_TRY(hipMalloc(&c->d_direct, c->tile_pixels * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->d_accum, c->tile_pixels * sizeof(float4)));
-    HIP_TRY(hipMemsetAsync(c->d_direct, 0, c->tile_pixels * sizeof(float4), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
+    c->plan.tile_pixels = (size_t)c->frame.tw * c->frame.th;
+    if (!c->plan.tile_pixels) { c->plan.set_tile(0, 0); return 0; }
+    HIP_TRY(hipMalloc(&c->d_direct, c->plan.tile_pixels * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->d_accum, c->plan.tile_pixels * sizeof(float4)));
+    HIP_TRY(hipMemsetAsync(c->d_direct, 0, c->plan.tile_pixels * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->plan.tile_pixels * sizeof(float4), c->stream));
     // wavefront path state: one slot per pixel of the 8x8-tile-padded tile, per pass in flight
     const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
     const size_t n = tiles * 64;
     if (n > 0xfffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");
-    c->n_slots = (uint32_t)n;
     // Several passes run through the pipeline together (slot = pass x pixel) while that stays within `batch_paths`
     // paths: a persistent k_trace wave then takes many rays per lane, and the drain at the end of every launch — waves
     // finishing their last, long rays with few lanes busy — shrinks relative to the useful work (SQ_INSTS_VALU per
-    // ray falls by a quarter from 2M to 16M paths per launch at 1080p).
-    size_t B = std::max<size_t>(1, std::min<size_t>(c->batch_limit, c->batch_paths / n));
-    if (n * B > 0x7ffffff0ull) return fail(GPUART_HIP_ERR_ARG, "tile too large");  // two queues share one 32-bit index space in k_trace
+    // ray falls by a quarter from 2M to 16M paths per launch at 1080p). run_planner.h decides how many.
+    if (n * std::max<size_t>(1, std::min<size_t>(c->plan.batch_limit, c->plan.batch_paths / n)) > 0x7ffffff0ull)
+        return fail(GPUART_HIP_ERR_ARG, "tile too large");  // two queues share one 32-bit index space in k_trace
     for (auto &l : c->lanes) {
         if (l.pathmem) { (void)hipFree(l.pathmem); l.pathmem = nullptr; }
         l.used = false;
     }
     c->next_lane = 0;
+    c->pend_seeds.clear();
+    c->plan.set_tile((uint32_t)n, c->plan.tile_pixels);
     // Lanes within the memory budget; when the device cannot give that much (other tenants), fewer lanes and then
     // smaller runs are tried before giving up — results do not depend on either.
-    size_t lanes = 0, bytes = 0;
     for (;;) {
-        bytes = n * B * (6 * sizeof(float4) + sizeof(uint2) + 3 * sizeof(uint32_t)) + B * c->tile_pixels * sizeof(float4);
-        if (!lanes) lanes = std::min<size_t>(c->lanes.size(), std::max<size_t>(2, c->lane_budget / bytes));
+        const size_t bytes = c->plan.lane_bytes(c->plan.max_batch);
         size_t got = 0;
-        while (got < lanes && hipMalloc(&c->lanes[got].pathmem, bytes) == hipSuccess) got++;
-        if (got == lanes) break;
+        while (got < c->plan.lanes_in_use && hipMalloc(&c->lanes[got].pathmem, bytes) == hipSuccess) got++;
+        if (got == c->plan.lanes_in_use) break;
         (void)hipGetLastError();  // clear the out-of-memory error
         for (size_t li = 0; li < got; li++) { (void)hipFree(c->lanes[li].pathmem); c->lanes[li].pathmem = nullptr; }
-        if (lanes > 2) lanes = std::max<size_t>(2, lanes / 2);
-        else if (B > 1) { B = (B + 1) / 2; lanes = 0; }
-        else if (lanes > 1) lanes = 1;
-        else return fail(GPUART_HIP_ERR_DEVICE, "out of device memory for the path state of one pass");
+        if (!c->plan.shrink()) return fail(GPUART_HIP_ERR_DEVICE, "out of device memory for the path state of one pass");
     }
-    c->max_batch = (uint32_t)B;
-    c->lanes_in_use = (uint32_t)lanes;
-    plan_runs(c);
+    const size_t B = c->plan.max_batch, lanes = c->plan.lanes_in_use;
     for (size_t li = 0; li < lanes; li++) {
         PassLane &l = c->lanes[li];
         char *m = (char *)l.pathmem;
@@ -239,14 +206,14 @@ int realloc_tile(gpuart_hip_ctx *c) {
         b.pc = (float4 *)m; m += nb * sizeof(float4);
         b.sun = (float4 *)m; m += nb * sizeof(float4);
         b.color = (float4 *)m; m += nb * sizeof(float4);
-        l.passcolor = (float4 *)m; m += B * c->tile_pixels * sizeof(float4);
+        l.passcolor = (float4 *)m; m += B * c->plan.tile_pixels * sizeof(float4);
         b.hit = (uint2 *)m; m += nb * sizeof(uint2);
         b.queue[0] = (uint32_t *)m; m += nb * sizeof(uint32_t);
         b.queue[1] = (uint32_t *)m; m += nb * sizeof(uint32_t);
         b.shadow_queue = (uint32_t *)m;
         b.n_slots = (uint32_t)n;
         b.batch = 1;
-        b.tile_pixels = (uint32_t)c->tile_pixels;
+        b.tile_pixels = (uint32_t)c->plan.tile_pixels;
     }
     return 0;
 }
@@ -411,13 +378,15 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
-    c->batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
-    c->batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
-    c->plan_run_factor = env_u32("GPUART_HIP_PLAN_RUN_PERCENT", 75, 1, 1000) / 100.0;
+    c->plan.lanes_total = (uint32_t)c->lanes.size();
+    c->plan.batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
+    c->plan.batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
+    c->plan.plan_run_factor = env_u32("GPUART_HIP_PLAN_RUN_PERCENT", 75, 1, 1000) / 100.0;
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
-    c->min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
-    c->lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
-    c->small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 6400, 0, 1 << 20) << 10;
+    c->plan.min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
+    c->plan.lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
+    c->plan.small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 6400, 0, 1 << 20) << 10;
+    c->gather_timeout_ms = env_u32("GPUART_HIP_GATHER_TIMEOUT_MS", 60000, 0, 3600000);
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -450,7 +419,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     }
     if (c->comm && c->comm_owned && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
     void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor,
-                    c->d_send, c->d_stage, c->d_geoms};
+                    c->d_send, c->d_stage, c->d_hello};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -531,25 +500,26 @@ int gpuart_hip_set_camera(gpuart_hip_ctx *c, const float pos[3], const float bl[
 
 static int check_ready(gpuart_hip_ctx *c, const gpuart_params *p) {
     if (!c || !p) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (c->empty_share) return 1;  // nothing to render (the callers return success)
     if (!c->have_scene) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
     if (!c->have_camera) return fail(GPUART_HIP_ERR_ARG, "no camera set");
-    if (!c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    if (!c->plan.tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
     return 0;
 }
 
 int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
     int r = check_ready(c, p);
-    if (r) return r;
+    if (r) return r > 0 ? 0 : r;
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     HIP_TRY(hipSetDevice(c->device));
-    dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
+    dim3 grid(std::min<uint32_t>(c->grid_waves, c->plan.n_slots / BLOCK));
     Scene sc = scene_of(c);
     TimedLaunch t;
     if ((r = begin_timed(c, t, 0))) return r;
-    if (c->mode == 1) {
-        k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
-    } else if (c->mode == 2) {
-        k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_counters);
+    if (c->plan.mode == 1) {
+        k_direct<true><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->plan.n_slots, c->d_direct, c->d_spill, c->d_counters);
+    } else if (c->plan.mode == 2) {
+        k_direct<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->plan.n_slots, c->d_direct, c->d_spill, c->d_counters);
     } else {
         // fast mode: persistent lanes, one pixel at a time per lane (kernels_pipeline.h)
         if (!c->d_cursor) HIP_TRY(hipMalloc(&c->d_cursor, 64));
@@ -559,13 +529,13 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
         // dependent queries). Small frames take 64-pixel chunks — 1080p 0.92 -> 0.75 ms per frame; 4K stays at 128 (1.74 against
         // 1.85): fewer cursor atomics, longer coherent runs (gpurun_out/direct_chunk.txt; 32 and 16 are far worse: 1.0 / 1.7 ms)
         TraceTuning dtune = c->tune;
-        if (!c->chunk_from_env && c->n_slots / ((size_t)c->direct_waves * 8) < 128) dtune.chunk = 64;
+        if (!c->chunk_from_env && c->plan.n_slots / ((size_t)c->direct_waves * 8) < 128) dtune.chunk = 64;
         const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;
         const bool round_only = c->lean_kernels && !c->exact_boxes && !flat_only && (c->type_mask & ~(uint32_t)GD_ROUND_TYPES) == 0;
-        if (c->exact_boxes) k_direct_persistent<GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
-        else if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
-        else if (round_only) k_direct_persistent<GD_ROUND_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
-        else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        if (c->exact_boxes) k_direct_persistent<GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->plan.n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        else if (flat_only) k_direct_persistent<GD_FLAT_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->plan.n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        else if (round_only) k_direct_persistent<GD_ROUND_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->plan.n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
+        else k_direct_persistent<GD_ALL_TYPES><<<pgrid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, c->plan.n_slots, c->d_direct, c->d_spill, c->d_cursor, dtune);
     }
     HIP_TRY(hipGetLastError());
     return end_timed(c, t);
@@ -573,19 +543,20 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
 
 int gpuart_hip_pt_plan(gpuart_hip_ctx *c, uint32_t passes) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
-    c->planned_passes = passes;
-    plan_runs(c);
+    c->plan.planned_passes = passes;
+    c->plan.plan();
     return 0;
 }
 
 int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
-    if (!c || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    if (c && c->empty_share) return 0;
+    if (!c || !c->plan.tile_pixels) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     // passes still in flight belong to the accumulation that is being discarded: let them finish first
     int r = drain(c);
     if (r) return r;
-    HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->tile_pixels * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->plan.tile_pixels * sizeof(float4), c->stream));
     return 0;
 }
 
@@ -616,20 +587,8 @@ static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
     return std::max<uint32_t>(bound, 1);
 }
 
+extern "C++" {
 namespace {
-/// Whether a run of `count` passes goes through the persistent run kernel (k_run) rather than the launch pipeline.
-/// Measured on cfg3 (profiles/r02/k_run_vs_pipeline.txt): one pass alone 2.2 vs 3.4 ms, two 1.65 vs 1.98, three 1.47 vs 1.56, four
-/// 1.36 vs 1.31, 64 1.19 vs 0.93 ms per pass — k_run has no chain of dependent launches, the pipeline packs lanes better once several
-/// runs overlap. Mode 0 therefore uses k_run when the whole planned sequence is small (an interactive frame); GPUART_HIP_SMALL_KPATHS=0
-/// turns that off altogether.
-bool uses_run_kernel(const gpuart_hip_ctx *c, size_t count) {
-    if (c->mode == 1 || c->mode == 4 || c->mode == 5) return true;
-    if (c->mode != 0 || !c->small_paths) return false;
-    const size_t passes = c->planned_passes ? c->planned_passes : count;
-    // one pass observed alone: k_run at every frame size (4K: 5.7 against 8.2 ms); a short sequence while it is small
-    return passes <= 1 || passes * (size_t)c->n_slots <= c->small_paths;
-}
-
 /// The collected passes [first, first + count) as ONE persistent kernel per path of the pass (k_run, kernel_run.h) on
 /// pass lane `l`; then their colour planes are added to the accumulator in pass order on the primary stream.
 int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t count) {
@@ -653,11 +612,11 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
         TimedLaunch tt;
         HIP_TRY(hipMemsetAsync(l.run_cursor, 0, sizeof(uint32_t), l.main));
         if (c->timing_level >= 2 && (r = begin_timed(c, tt, 1, l.main))) return r;
-        if (c->mode == 1 && exact) k_run<true, true, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->mode == 1) k_run<true, true, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->mode == 4 && flat_only) k_run<true, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->mode == 4 && exact) k_run<true, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->mode == 4) k_run<true, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        if (c->plan.mode == 1 && exact) k_run<true, true, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->plan.mode == 1) k_run<true, true, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->plan.mode == 4 && flat_only) k_run<true, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->plan.mode == 4 && exact) k_run<true, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
+        else if (c->plan.mode == 4) k_run<true, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (flat_only) k_run<false, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (round_only) k_run<false, false, GD_ROUND_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
         else if (exact) k_run<false, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
@@ -668,7 +627,7 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     if ((r = end_timed(c, t, l.main))) return r;
     HIP_TRY(hipEventRecord(l.ev_done, l.main));
     HIP_TRY(hipStreamWaitEvent(c->stream, l.ev_done, 0));
-    k_accumulate<<<dim3((unsigned)((c->tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->tile_pixels, b.batch);
+    k_accumulate<<<dim3((unsigned)((c->plan.tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->plan.tile_pixels, b.batch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(l.ev_free, c->stream));
     l.used = true;
@@ -683,12 +642,12 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     const int npaths = c->pend_npaths;
     Scene sc = scene_of(c);
     TimedLaunch t;
-    // a lane's path buffers hold max_batch passes (realloc_tile): a longer run would write past them
-    if (!count || count > c->max_batch) return fail(GPUART_HIP_ERR_DEVICE, "internal: a pipeline run longer than its lane's buffers");
+    // a lane's path buffers hold max_batch passes (realloc_tile): a longer run would write past them (run_planner.h)
+    if (const char *bad = c->plan.check(count)) return fail(GPUART_HIP_ERR_DEVICE, std::string("internal: ") + bad);
     PassLane &l = c->lanes[c->next_lane];
-    c->next_lane = (c->next_lane + 1) % c->lanes_in_use;
+    c->next_lane = (c->next_lane + 1) % c->plan.lanes_in_use;
     l.pb.batch = (uint32_t)count;
-    if (uses_run_kernel(c, count)) return launch_run_persistent(c, l, first, count);
+    if (c->plan.uses_run_kernel(count)) return launch_run_persistent(c, l, first, count);
     const uint32_t nseg = segment_bound(c, p);
     SeedBatch seeds{};
     for (size_t k = 0; k < count; k++) seeds.seed[k] = c->pend_seeds[first + k];
@@ -731,28 +690,27 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     // accumulate in pass order on the primary stream, then release the lane
     HIP_TRY(hipEventRecord(l.ev_done, l.main));
     HIP_TRY(hipStreamWaitEvent(c->stream, l.ev_done, 0));
-    k_accumulate<<<dim3((unsigned)((c->tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->tile_pixels, b.batch);
+    k_accumulate<<<dim3((unsigned)((c->plan.tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->plan.tile_pixels, b.batch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(l.ev_free, c->stream));
     l.used = true;
     return 0;
 }
 }  // namespace
+}  // extern "C++"
 
 int gpuart_hip_flush(gpuart_hip_ctx *c) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
     const size_t pending = c->pend_seeds.size();
     if (!pending) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    // What is still pending when something observes or changes state (read-back, finish, ...) is split into runs of
-    // at least ~2M paths on separate pass lanes, so that the end of a pass sequence still overlaps its kernels.
-    // (k_run fills the machine by itself: one run.)
-    const size_t runs = uses_run_kernel(c, pending) ? 1 :
-        std::max<size_t>(1, std::min<size_t>({(size_t)c->lanes_in_use, pending, pending * c->n_slots / c->min_run_paths}));
+    // What is still pending when something observes or changes state (read-back, finish, ...) is split into runs
+    // (RunPlanner::on_flush)
+    c->plan.pending = pending;
     int r = 0;
-    for (size_t k = 0, first = 0; k < runs && !r; k++) {
-        const size_t count = (pending - first) / (runs - k);
-        r = launch_run(c, first, count);
+    size_t first = 0;
+    for (size_t count : c->plan.on_flush()) {
+        if ((r = launch_run(c, first, count))) break;
         first += count;
     }
     c->pend_seeds.clear();
@@ -762,19 +720,19 @@ int gpuart_hip_flush(gpuart_hip_ctx *c) {
 
 int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float randSeed[4], int npaths) {
     int r = check_ready(c, p);
-    if (r) return r;
+    if (r) return r > 0 ? 0 : r;
     if (!randSeed || npaths < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     if (p->maxSegments > GPUART_HIP_MAX_SEGMENTS) return fail(GPUART_HIP_ERR_ARG, "maxSegments exceeds GPUART_HIP_MAX_SEGMENTS");
     if (npaths == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     const float4 seed = make_float4(randSeed[0], randSeed[1], randSeed[2], randSeed[3]);
-    if (c->mode == 2) {  // megakernel: the whole path in one thread, on the primary stream (ablation / cross-check)
+    if (c->plan.mode == 2) {  // megakernel: the whole path in one thread, on the primary stream (ablation / cross-check)
         if ((r = gpuart_hip_flush(c))) return r;
         Scene sc = scene_of(c);
         TimedLaunch t;
         if ((r = begin_timed(c, t, 0))) return r;
-        dim3 grid(std::min<uint32_t>(c->grid_waves, c->n_slots / BLOCK));
-        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->n_slots, c->d_accum, c->d_spill, c->d_counters);
+        dim3 grid(std::min<uint32_t>(c->grid_waves, c->plan.n_slots / BLOCK));
+        k_pt_mega<false><<<grid, BLOCK, 0, c->stream>>>(sc, c->frame, *p, seed, npaths, c->plan.n_slots, c->d_accum, c->d_spill, c->d_counters);
         HIP_TRY(hipGetLastError());
         return end_timed(c, t);
     }
@@ -785,8 +743,9 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
     c->pend_params = *p;
     c->pend_npaths = npaths;
     c->pend_seeds.push_back(seed);
-    if (c->pend_seeds.size() >= c->run_passes) {
-        r = launch_run(c, 0, c->pend_seeds.size());
+    c->plan.pending = c->pend_seeds.size() - 1;
+    if (const size_t count = c->plan.on_pass()) {
+        r = launch_run(c, 0, count);
         c->pend_seeds.clear();
         return r;
     }
@@ -794,22 +753,22 @@ int gpuart_hip_pt_pass(gpuart_hip_ctx *c, const gpuart_params *p, const float ra
 }
 
 int gpuart_hip_export(gpuart_hip_ctx *c, int which, void *rgba_device, float divide_by) {
-    if (!c || !rgba_device || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (!c || !rgba_device || (which != 0 && which != 1) || !c->plan.tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     const float4 *src = which == 0 ? c->d_direct : c->d_accum;
     if (!(divide_by > 0)) divide_by = 1.0f;
-    size_t n = c->tile_pixels;
+    size_t n = c->plan.tile_pixels;
     k_scale_copy<<<dim3((unsigned)((n + 255) / 256)), 256, 0, c->stream>>>(src, (float4 *)rgba_device, n, divide_by);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int gpuart_hip_read(gpuart_hip_ctx *c, int which, float *rgba_host, float divide_by) {
-    if (!c || !rgba_host || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (!c || !rgba_host || (which != 0 && which != 1) || !c->plan.tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
-    size_t bytes = c->tile_pixels * sizeof(float4);
+    size_t bytes = c->plan.tile_pixels * sizeof(float4);
     const float4 *src = which == 0 ? c->d_direct : c->d_accum;
     if (divide_by > 0 && divide_by != 1.0f) {
         int r = ensure_scratch(c, bytes);
@@ -824,10 +783,10 @@ int gpuart_hip_read(gpuart_hip_ctx *c, int which, float *rgba_host, float divide
 }
 
 int gpuart_hip_write(gpuart_hip_ctx *c, int which, const float *rgba_host) {
-    if (!c || !rgba_host || which != 1 || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    if (!c || !rgba_host || which != 1 || !c->plan.tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
-    HIP_TRY(hipMemcpyAsync(c->d_accum, rgba_host, c->tile_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_accum, rgba_host, c->plan.tile_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -845,8 +804,8 @@ int gpuart_hip_set_mode(gpuart_hip_ctx *c, int mode) {
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }
     int r = drain(c);  // modes use different streams; keep their passes ordered
     if (r) return r;
-    c->mode = mode;
-    plan_runs(c);
+    c->plan.mode = mode;
+    c->plan.plan();
     return 0;
 }
 
@@ -900,9 +859,17 @@ int gpuart_hip_scene_info(gpuart_hip_ctx *c, uint64_t *nodes, uint64_t *prims, u
 
 // ---- shares and the multi-GPU gather (gather.h) ---------------------------------------------------------------------
 int gpuart_hip_set_share(gpuart_hip_ctx *c, const gpuart_tile_geom *g) {
-    if (!c || !g || !geom_ok(*g) || !g->th) return fail(GPUART_HIP_ERR_ARG, "bad share");
+    if (!c || !g || !geom_ok(*g)) return fail(GPUART_HIP_ERR_ARG, "bad share");
     if (g->W != c->frame.W || g->H != c->frame.H) return fail(GPUART_HIP_ERR_ARG, "share of another frame size (call gpuart_hip_resize first)");
-    return gpuart_hip_set_tile_interleaved(c, g->x0, g->y0, g->tw, g->th, g->band_rows, g->band_stride);
+    if (g->th) return gpuart_hip_set_tile_interleaved(c, g->x0, g->y0, g->tw, g->th, g->band_rows, g->band_stride);
+    // An empty share (more ranks than bands): the context renders nothing — render calls succeed and do nothing — and still
+    // takes part in gpuart_hip_gather, where it sends nothing.
+    HIP_TRY(hipSetDevice(c->device));
+    c->frame.x0 = g->x0; c->frame.y0 = g->y0; c->frame.tw = g->tw; c->frame.th = 0;
+    c->frame.band_rows = g->band_rows; c->frame.band_stride = g->band_stride;
+    int r = realloc_tile(c);
+    c->empty_share = r == 0;
+    return r;
 }
 
 int gpuart_hip_get_share(gpuart_hip_ctx *c, gpuart_tile_geom *g) {
@@ -988,6 +955,7 @@ int gpuart_hip_comm_destroy(gpuart_hip_ctx *c) {
     return 0;
 }
 
+extern "C++" {
 namespace {
 int ensure_pixels(float4 *&buf, size_t &have, size_t want) {
     if (have >= want && buf) return 0;
@@ -997,77 +965,158 @@ int ensure_pixels(float4 *&buf, size_t &have, size_t want) {
     return 0;
 }
 
-/// One rank's part of a gather, to be called between ncclGroupStart and ncclGroupEnd: exports the (divided) tile and
-/// posts the send, or — on the root — the receives into the staging buffer. `all` = every rank's share.
-int gather_post(gpuart_hip_ctx *c, int which, float divide_by, int root, const std::vector<gpuart_tile_geom> &all) {
+/// What every rank tells the others before anything is sent: its share and whether it is able to take part.
+struct GatherHello {
+    gpuart_tile_geom g;
+    uint32_t status;  ///< 0: ready; else the rank could not prepare (out of memory, bad arguments): nobody posts a transfer
+    uint32_t which, root, pad;
+};
+static_assert(sizeof(GatherHello) == 48, "all-gathered as 12 words per rank");
+
+/// Everything of a gather that can fail on THIS rank alone, done before the ranks commit to a transfer: pending passes are
+/// launched, the (divided) tile is exported into the rank's send buffer, and the root's staging area — one frame, whatever the
+/// shares turn out to be — exists. The verdict travels with the share (GatherHello::status), so that a rank that cannot go on
+/// makes every rank return an error instead of leaving its peers blocked in a receive.
+int gather_prepare(gpuart_hip_ctx *c, int which, float divide_by, int root, GatherHello &h) {
     int r;
-    const int n = c->comm_nranks, me = c->comm_rank;
-    const size_t mine = (size_t)all[me].tw * all[me].th;
-    if (mine != c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "share table does not match this context's tile");
-    if (me != root) {
-        if ((r = ensure_pixels(c->d_send, c->send_pixels, mine))) return r;
+    memset(&h, 0, sizeof h);
+    h.which = (uint32_t)which; h.root = (uint32_t)root;
+    if ((r = gpuart_hip_get_share(c, &h.g))) return r;
+    if ((r = gpuart_hip_flush(c))) return r;
+    if (c->plan.tile_pixels) {
+        if ((r = ensure_pixels(c->d_send, c->send_pixels, c->plan.tile_pixels))) return r;
         if ((r = gpuart_hip_export(c, which, c->d_send, divide_by))) return r;
-        NCCL_TRY(rccl()->Send(c->d_send, mine * 4, ncclFloat, root, c->comm, c->stream));
-        return 0;
     }
-    size_t total = 0;
-    for (int k = 0; k < n; k++) total += (size_t)all[k].tw * all[k].th;
-    if ((r = ensure_pixels(c->d_stage, c->stage_pixels, total))) return r;
-    size_t off = 0;
-    for (int k = 0; k < n; k++) {
-        const size_t cnt = (size_t)all[k].tw * all[k].th;
-        if (k == me) { if ((r = gpuart_hip_export(c, which, c->d_stage + off, divide_by))) return r; }
-        else if (cnt) NCCL_TRY(rccl()->Recv(c->d_stage + off, cnt * 4, ncclFloat, k, c->comm, c->stream));
-        off += cnt;
-    }
+    if (c->comm_rank == root && (r = ensure_pixels(c->d_stage, c->stage_pixels, (size_t)c->frame.W * c->frame.H))) return r;
     return 0;
 }
 
-/// After the group: the root scatters every share's rows into the full frame.
-int gather_place(gpuart_hip_ctx *c, const std::vector<gpuart_tile_geom> &all, float4 *full) {
+/// The shares of all ranks must be full-width rows of one frame that cover every row exactly once: rows nobody renders would
+/// stay uninitialised in the root's frame, rows rendered twice would depend on the order of the transfers.
+int check_shares(const std::vector<GatherHello> &all, int which, int root) {
+    const gpuart_tile_geom &g0 = all[0].g;
+    std::vector<uint8_t> cover(g0.H, 0);
+    for (size_t k = 0; k < all.size(); k++) {
+        const gpuart_tile_geom &g = all[k].g;
+        if (all[k].status) return fail(GPUART_HIP_ERR_DEVICE, "gather: rank " + std::to_string(k) + " could not prepare its share (its own call reports why)");
+        if ((int)all[k].which != which || (int)all[k].root != root) return fail(GPUART_HIP_ERR_ARG, "gather: the ranks disagree about buffer or root");
+        if (!geom_ok(g) || g.W != g0.W || g.H != g0.H) return fail(GPUART_HIP_ERR_ARG, "gather: inconsistent shares");
+        if (g.th && (g.x0 != 0 || g.tw != g.W)) return fail(GPUART_HIP_ERR_ARG, "gather: shares must be full-width rows");
+        for (uint32_t ly = 0; ly < g.th; ly++) {
+            uint8_t &n = cover[gpuart_hip_frame_row(&g, ly)];
+            if (n) return fail(GPUART_HIP_ERR_ARG, "gather: shares overlap (a frame row belongs to two ranks)");
+            n = 1;
+        }
+    }
+    for (uint32_t y = 0; y < g0.H; y++)
+        if (!cover[y]) return fail(GPUART_HIP_ERR_ARG, "gather: frame row " + std::to_string(y) + " belongs to no rank");
+    return 0;
+}
+
+/// One rank's transfers, between ncclGroupStart and ncclGroupEnd; nothing in here can fail for a reason of this rank alone
+/// (buffers exist, shares are validated): a peer posts its send, the root its receives into the staging area.
+ncclResult_t gather_post(gpuart_hip_ctx *c, int root, const std::vector<GatherHello> &all) {
+    const int n = (int)all.size(), me = c->comm_rank;
+    if (me != root) {
+        if (!c->plan.tile_pixels) return ncclSuccess;  // an empty share (more ranks than bands)
+        return rccl()->Send(c->d_send, c->plan.tile_pixels * 4, ncclFloat, root, c->comm, c->stream);
+    }
     size_t off = 0;
-    for (const gpuart_tile_geom &g : all) {
+    for (int k = 0; k < n; k++) {
+        const size_t cnt = (size_t)all[k].g.tw * all[k].g.th;
+        if (k != me && cnt) {
+            const ncclResult_t e = rccl()->Recv(c->d_stage + off, cnt * 4, ncclFloat, k, c->comm, c->stream);
+            if (e != ncclSuccess) return e;
+        }
+        off += cnt;
+    }
+    return ncclSuccess;
+}
+
+/// After the group: the root scatters every share's rows into the full frame (its own straight from its send buffer).
+int gather_place(gpuart_hip_ctx *c, const std::vector<GatherHello> &all, float4 *full) {
+    size_t off = 0;
+    for (size_t k = 0; k < all.size(); k++) {
+        const gpuart_tile_geom &g = all[k].g;
         const size_t cnt = (size_t)g.tw * g.th;
-        if (cnt) k_scatter_rows<<<dim3((unsigned)((cnt + 255) / 256)), 256, 0, c->stream>>>(g, c->d_stage + off, full);
+        const float4 *src = (int)k == c->comm_rank ? c->d_send : c->d_stage + off;
+        if (cnt) k_scatter_rows<<<dim3((unsigned)((cnt + 255) / 256)), 256, 0, c->stream>>>(g, src, full);
         off += cnt;
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int check_shares(const std::vector<gpuart_tile_geom> &all) {
-    uint64_t pixels = 0;
-    for (const gpuart_tile_geom &g : all) {
-        if (!geom_ok(g) || g.W != all[0].W || g.H != all[0].H) return fail(GPUART_HIP_ERR_ARG, "inconsistent shares");
-        pixels += (uint64_t)g.tw * g.th;
+/// Waits for the context's primary stream, but not for ever: a peer that never arrives must not hang this process.
+int wait_stream(gpuart_hip_ctx *c, uint32_t timeout_ms, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(GPUART_HIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+        if (timeout_ms && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms))
+            return fail(GPUART_HIP_ERR_TIMEOUT, std::string(what) + ": not complete after " + std::to_string(timeout_ms) +
+                        " ms (rank " + std::to_string(c->comm_rank) + " of " + std::to_string(c->comm_nranks) + "; a peer has not joined the collective)");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
-    if (pixels > (uint64_t)all[0].W * all[0].H) return fail(GPUART_HIP_ERR_ARG, "shares overlap");
-    return 0;
 }
 }  // namespace
+}  // extern "C++"
+
+int gpuart_hip_comm_info(gpuart_hip_ctx *c, int *nranks, int *rank) {
+    if (!c || !c->comm) return fail(GPUART_HIP_ERR_ARG, "no communicator (gpuart_hip_comm_init)");
+    int r = need_rccl();
+    if (r) return r;
+    int n = 0, me = 0;
+    NCCL_TRY(rccl()->CommCount(c->comm, &n));
+    NCCL_TRY(rccl()->CommUserRank(c->comm, &me));
+    if (nranks) *nranks = n;
+    if (rank) *rank = me;
+    return 0;
+}
+
+int gpuart_hip_wait(gpuart_hip_ctx *c, uint32_t timeout_ms) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }
+    // the pass lanes' work reaches the primary stream through their events (accumulation in pass order), so the primary stream
+    // is the last to finish
+    int r = wait_stream(c, timeout_ms, "gpuart_hip_wait");
+    return r ? r : drain(c);
+}
 
 int gpuart_hip_gather(gpuart_hip_ctx *c, int which, float divide_by, int root, void *full_frame_device) {
     if (!c || !c->comm) return fail(GPUART_HIP_ERR_ARG, "no communicator (gpuart_hip_comm_init)");
-    if (root < 0 || root >= c->comm_nranks || (which != 0 && which != 1) || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "bad argument");
-    if (c->comm_rank == root && !full_frame_device) return fail(GPUART_HIP_ERR_ARG, "the root needs a frame buffer");
+    if (c->comm_nranks > 1024) return fail(GPUART_HIP_ERR_ARG, "more than 1024 ranks");
     HIP_TRY(hipSetDevice(c->device));
-    int r;
     const int n = c->comm_nranks;
-    // everybody's share, through the communicator itself (8 words per rank)
-    if (!c->d_geoms) HIP_TRY(hipMalloc(&c->d_geoms, (size_t)(1 + 1024) * sizeof(gpuart_tile_geom)));
-    if (n > 1024) return fail(GPUART_HIP_ERR_ARG, "more than 1024 ranks");
-    gpuart_tile_geom own;
-    if ((r = gpuart_hip_get_share(c, &own))) return r;
-    std::vector<gpuart_tile_geom> all(n);
-    HIP_TRY(hipMemcpyAsync(c->d_geoms, &own, sizeof own, hipMemcpyHostToDevice, c->stream));
-    NCCL_TRY(rccl()->AllGather(c->d_geoms, c->d_geoms + 1, sizeof own / 4, ncclUint32, c->comm, c->stream));
-    HIP_TRY(hipMemcpyAsync(all.data(), c->d_geoms + 1, (size_t)n * sizeof own, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((r = check_shares(all))) return r;
-    NCCL_TRY(rccl()->GroupStart());
-    r = gather_post(c, which, divide_by, root, all);
-    ncclResult_t ge = rccl()->GroupEnd();
+    // 1. everything that can fail here alone; the verdict is part of what the ranks exchange
+    GatherHello own;
+    int mine = 0;
+    if (root < 0 || root >= n || (which != 0 && which != 1)) mine = fail(GPUART_HIP_ERR_ARG, "bad argument");
+    else if (c->comm_rank == root && !full_frame_device) mine = fail(GPUART_HIP_ERR_ARG, "the root needs a frame buffer");
+    else mine = gather_prepare(c, which, divide_by, root, own);
+    const std::string my_error = mine ? g_last_error : std::string();
+    if (mine) { memset(&own, 0, sizeof own); own.which = (uint32_t)which; own.root = (uint32_t)root; }
+    own.status = mine ? 1u : 0u;
+    if (!c->d_hello && hipMalloc(&c->d_hello, (size_t)(1 + 1024) * sizeof(GatherHello)) != hipSuccess)
+        return fail(GPUART_HIP_ERR_DEVICE, "gather: no device memory for the share table (the other ranks are left waiting: nothing can be told to them)");
+    // 2. everybody's share and status, through the communicator itself (12 words per rank)
+    std::vector<GatherHello> all((size_t)n);
+    GatherHello *d = (GatherHello *)c->d_hello;
+    HIP_TRY(hipMemcpyAsync(d, &own, sizeof own, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(rccl()->AllGather(d, d + 1, sizeof own / 4, ncclUint32, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(all.data(), d + 1, (size_t)n * sizeof own, hipMemcpyDeviceToHost, c->stream));
+    int r = wait_stream(c, c->gather_timeout_ms, "gather: exchange of the shares");
     if (r) return r;
+    if (mine) return fail(mine, my_error);
+    // 3. the same table on every rank: the same verdict on every rank
+    if ((r = check_shares(all, which, root))) return r;
+    // 4. the transfers
+    NCCL_TRY(rccl()->GroupStart());
+    const ncclResult_t pe = gather_post(c, root, all);
+    const ncclResult_t ge = rccl()->GroupEnd();
+    if (pe != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("gather: posting the transfers: ") + rccl()->GetErrorString(pe));
     if (ge != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
     if (c->comm_rank == root) return gather_place(c, all, (float4 *)full_frame_device);
     return 0;
@@ -1076,20 +1125,25 @@ int gpuart_hip_gather(gpuart_hip_ctx *c, int which, float divide_by, int root, v
 int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, void *full_frame_device) {
     if (!ctxs || n < 1 || root < 0 || root >= n || !full_frame_device || (which != 0 && which != 1)) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     int r;
-    std::vector<gpuart_tile_geom> all(n);
+    std::vector<GatherHello> all((size_t)n);
+    // one thread drives every rank: all local preparation first, transfers only when every rank is ready
     for (int k = 0; k < n; k++) {
         if (!ctxs[k] || !ctxs[k]->comm || ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k)
-            return fail(GPUART_HIP_ERR_ARG, "contexts are not the ranks 0..n-1 of one communicator (gpuart_hip_comm_init_all)");
-        if ((r = gpuart_hip_get_share(ctxs[k], &all[k]))) return r;
+            return fail(GPUART_HIP_ERR_NO_COMM, "contexts are not the ranks 0..n-1 of one communicator (gpuart_hip_comm_init_all)");
     }
-    if ((r = check_shares(all))) return r;
+    for (int k = 0; k < n; k++) {
+        HIP_TRY(hipSetDevice(ctxs[k]->device));
+        if ((r = gather_prepare(ctxs[k], which, divide_by, root, all[(size_t)k]))) return r;
+    }
+    if ((r = check_shares(all, which, root))) return r;
     NCCL_TRY(rccl()->GroupStart());
-    for (int k = 0; k < n && !r; k++) {
-        if (hipSetDevice(ctxs[k]->device) != hipSuccess) r = fail(GPUART_HIP_ERR_DEVICE, "hipSetDevice failed");
-        else r = gather_post(ctxs[k], which, divide_by, root, all);
+    ncclResult_t pe = ncclSuccess;
+    for (int k = 0; k < n && pe == ncclSuccess; k++) {
+        if (hipSetDevice(ctxs[k]->device) != hipSuccess) { pe = ncclUnhandledCudaError; break; }
+        pe = gather_post(ctxs[k], root, all);
     }
-    ncclResult_t ge = rccl()->GroupEnd();
-    if (r) return r;
+    const ncclResult_t ge = rccl()->GroupEnd();
+    if (pe != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("gather: posting the transfers: ") + rccl()->GetErrorString(pe));
     if (ge != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
     HIP_TRY(hipSetDevice(ctxs[root]->device));
     return gather_place(ctxs[root], all, (float4 *)full_frame_device);
@@ -1107,6 +1161,74 @@ int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, fl
     HIP_TRY(hipMemcpyAsync(full_frame_host, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// ---- run planner hook: the planner of the context, driven without a device (include/gpuart_hip.h) ---------------------
+int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_ops, uint32_t *runs, int max_runs) {
+    if (!cfg || (!ops && n_ops) || n_ops < 0 || (!runs && max_runs) || max_runs < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    RunPlanner p;
+    p.batch_limit = MAX_BATCH;
+    if (cfg[0]) p.batch_limit = std::min<uint32_t>(cfg[0], MAX_BATCH);
+    if (cfg[1]) p.lanes_total = std::min<uint32_t>(cfg[1], 32);
+    if (cfg[2]) p.batch_paths = (size_t)cfg[2] << 20;
+    if (cfg[3]) p.min_run_paths = (size_t)cfg[3] << 10;
+    if (cfg[4]) p.small_paths = cfg[4] == 0xffffffffu ? 0 : (size_t)cfg[4] << 10;
+    if (cfg[5]) p.lane_budget = (size_t)cfg[5] << 20;
+    if (cfg[6]) p.plan_run_factor = cfg[6] / 100.0;
+    uint32_t W = 0, H = 0, alloc_fails = 0;
+    int n_runs = 0;
+    auto record = [&](int op, size_t count) {
+        if (n_runs < max_runs) {
+            uint32_t *o = runs + 6 * (size_t)n_runs;
+            o[0] = (uint32_t)op; o[1] = p.n_slots; o[2] = p.max_batch; o[3] = (uint32_t)count;
+            o[4] = p.uses_run_kernel(count) ? 1u : 0u; o[5] = (uint32_t)p.pending;
+        }
+        n_runs++;
+    };
+    auto flush = [&](int op) { for (size_t count : p.on_flush()) record(op, count); };
+    auto tile = [&](int op, uint32_t tw, uint32_t th) -> int {
+        flush(op);  // realloc_tile: what is pending belongs to the old tile
+        const size_t n = (size_t)((tw + 7) / 8) * ((th + 7) / 8) * 64;
+        if (n > 0xfffffff0ull) return GPUART_HIP_ERR_ARG;
+        p.set_tile((uint32_t)n, (size_t)tw * th);
+        for (; alloc_fails; alloc_fails--)
+            if (!p.shrink()) return GPUART_HIP_ERR_DEVICE;
+        return 0;
+    };
+    for (int k = 0; k < n_ops; k++) {
+        const uint32_t op = ops[3 * k], a = ops[3 * k + 1], b = ops[3 * k + 2];
+        int r = 0;
+        switch (op) {
+        case 0:
+            if (!a || !b || a > 65536 || b > 65536) return fail(GPUART_HIP_ERR_ARG, "bad frame size");
+            W = a; H = b;
+            r = tile(k, W, H);
+            break;
+        case 1: {
+            gpuart_tile_geom g;
+            if (!W || gpuart_hip_share_of_rank(W, H, (int)a, (int)b, 8, &g) || !g.th) return fail(GPUART_HIP_ERR_ARG, "bad share");
+            r = tile(k, g.tw, g.th);
+            break;
+        }
+        case 2: p.planned_passes = a; p.plan(); break;
+        case 3:
+            if (a > 5) return fail(GPUART_HIP_ERR_ARG, "bad mode");
+            flush(k); p.mode = (int)a; p.plan();
+            break;
+        case 4:
+            if (!p.n_slots) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+            for (uint32_t i = 0; i < a; i++) {
+                if (p.mode == 2) continue;  // the megakernel renders a pass at once: nothing is collected
+                if (const size_t count = p.on_pass()) record(k, count);
+            }
+            break;
+        case 5: flush(k); break;
+        case 6: alloc_fails = a; break;
+        default: return fail(GPUART_HIP_ERR_ARG, "unknown planner op");
+        }
+        if (r) return fail(r, "planner: tile refused");
+    }
+    return n_runs;
 }
 
 // ---- test hooks ------------------------------------------------------------------------------------
@@ -1165,8 +1287,8 @@ int gpuart_hip_test_traverse(gpuart_hip_ctx *c, const float *rs, const float *rd
     });
 }
 int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
-    if (!c || !c->have_camera || !c->tile_pixels) return fail(GPUART_HIP_ERR_ARG, "camera / frame not set");
-    int n = (int)c->tile_pixels;
+    if (!c || !c->have_camera || !c->plan.tile_pixels) return fail(GPUART_HIP_ERR_ARG, "camera / frame not set");
+    int n = (int)c->plan.tile_pixels;
     float *outs[] = {rstart, rdir};
     Frame f = c->frame;
     return run_hook(c, n, nullptr, 0, outs, 2, [&](auto &, auto &o) { k_test_cam_rays<<<GRID1(n)>>>(f, o[0], o[1]); });

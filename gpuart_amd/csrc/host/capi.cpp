@@ -1,6 +1,7 @@
 // capi.cpp — flat C API over the C++ library (see capi.h).
 #include "capi.h"
 
+#include <system_error>
 #include <thread>
 #include "exact_sort.h"
 
@@ -36,9 +37,20 @@ template <class F>
 void in_parts(size_t n, F body) {
     const size_t parts = n >= 65536 ? 8 : 1;
     std::vector<std::thread> th;
-    for (size_t k = 1; k < parts; k++) th.emplace_back(body, n * k / parts, n * (k + 1) / parts);
+    struct Joiner {  // joins whatever was started, also when a part throws
+        std::vector<std::thread> &th;
+        ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+    } joiner{th};
+    th.reserve(parts);
+    for (size_t k = 1; k < parts; k++) {
+        const size_t a = n * k / parts, b = n * (k + 1) / parts;
+        try {
+            th.emplace_back(body, a, b);
+        } catch (const std::system_error &) {
+            body(a, b);  // no thread to be had (the GPU box's CPU share caps them): this part runs here
+        }
+    }
     body(0, n / parts);
-    for (auto &t : th) t.join();
 }
 
 bool make_list(const gpuart_prim_desc *prims, int n, std::vector<Primitive *> &out) {

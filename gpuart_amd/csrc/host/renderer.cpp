@@ -125,14 +125,15 @@ bool Renderer::GatherRadiance(Renderer *const *ranks, int n, int root, bool norm
         ctxs[(size_t)k] = ranks[k]->Backend;
     }
     Renderer &r0 = *ranks[root];
-    // one communicator per set of renderers; made on first use, kept by the contexts
-    static std::vector<gpuart_hip_ctx *> joined;
-    if (joined != ctxs) {
-        if (!r0.Check(gpuart_hip_comm_init_all(ctxs.data(), n), "creating the RCCL communicator")) return false;
-        joined = ctxs;
-    }
     const float div = normalized && r0.PathTracing.numPathsRendered ? (float)r0.PathTracing.numPathsRendered : 1.0f;
-    return r0.Check(gpuart_hip_gather_all_read(ctxs.data(), n, 1, div, root, fullFrame), "gathering the frame");
+    // One communicator per set of renderers, kept by the contexts themselves. Whether these contexts are (still) the ranks
+    // 0..n-1 of one is the library's to say: it answers GPUART_HIP_ERR_NO_COMM before anything is transferred, then one is made.
+    int rc = gpuart_hip_gather_all_read(ctxs.data(), n, 1, div, root, fullFrame);
+    if (rc == GPUART_HIP_ERR_NO_COMM) {
+        if (!r0.Check(gpuart_hip_comm_init_all(ctxs.data(), n), "creating the RCCL communicator")) return false;
+        rc = gpuart_hip_gather_all_read(ctxs.data(), n, 1, div, root, fullFrame);
+    }
+    return r0.Check(rc, "gathering the frame");
 }
 
 bool Renderer::SetCamera(const Camera &cam) {

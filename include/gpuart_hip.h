@@ -33,7 +33,9 @@ typedef enum gpuart_hip_status {
     GPUART_HIP_OK = 0,
     GPUART_HIP_ERR_ARG = -1,      /* bad argument / call order (e.g. render before upload) */
     GPUART_HIP_ERR_DEVICE = -2,   /* a HIP runtime call failed */
-    GPUART_HIP_ERR_NO_DEVICE = -3 /* no usable gfx950 device */
+    GPUART_HIP_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    GPUART_HIP_ERR_TIMEOUT = -4,  /* a bounded wait ran out (gpuart_hip_wait, the share exchange of gpuart_hip_gather): a peer is missing */
+    GPUART_HIP_ERR_NO_COMM = -5   /* the contexts are not (or no longer) the ranks of one communicator: make one and call again */
 } gpuart_hip_status;
 
 /* The uniforms of the reference's directLighting / pathTracing programs
@@ -153,12 +155,20 @@ int gpuart_hip_comm_init(gpuart_hip_ctx *ctx, int nranks, int rank, const void *
 int gpuart_hip_comm_attach(gpuart_hip_ctx *ctx, void *nccl_comm, int nranks, int rank);
 int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n);
 int gpuart_hip_comm_destroy(gpuart_hip_ctx *ctx);
+/* What the communicator itself says (ncclCommCount, ncclCommUserRank); GPUART_HIP_ERR_ARG without one. */
+int gpuart_hip_comm_info(gpuart_hip_ctx *ctx, int *nranks, int *rank);
 
 /* Collective over the communicator: every rank contributes buffer `which` (0 direct lighting, 1 accumulator) of its share,
  * divided by `divide_by`; on `root`, full_frame_device (W*H*4 floats in the root's device memory, frame row order) receives
  * the assembled frame (other ranks pass NULL). Shares are exchanged through the communicator itself. Asynchronous on the
  * contexts' streams after a short host synchronisation: call gpuart_hip_finish on the root before using the frame.
  * gpuart_hip_gather_all is the same for the ranks 0..n-1 of a gpuart_hip_comm_init_all communicator, from one thread. */
+/* Failure behaviour: everything that can fail on one rank alone (pending passes, buffers, arguments) happens BEFORE the
+ * ranks commit to a transfer, and its verdict travels with the share, so a rank that cannot take part makes every rank
+ * return an error rather than leaving its peers blocked in a receive. The shares must be full-width rows covering every frame
+ * row exactly once (gpuart_hip_share_of_rank; a rank beyond the number of bands holds an empty share and sends nothing). The
+ * host-side wait for the share exchange is bounded (GPUART_HIP_GATHER_TIMEOUT_MS, default 60 000, 0 = unbounded):
+ * GPUART_HIP_ERR_TIMEOUT means a peer never entered the collective. */
 int gpuart_hip_gather(gpuart_hip_ctx *ctx, int which, float divide_by, int root, void *full_frame_device);
 int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, void *full_frame_device);
 /* gpuart_hip_gather_all into host memory (W*H*4 floats): the frame is assembled on the root's device, then read back. */
@@ -173,6 +183,9 @@ int gpuart_hip_flush(gpuart_hip_ctx *ctx);
 
 /* glFinish() equivalent (reference src/main.cpp:564,584). */
 int gpuart_hip_finish(gpuart_hip_ctx *ctx);
+/* gpuart_hip_finish with a bound: GPUART_HIP_ERR_TIMEOUT if the context's work (e.g. the transfers of a gather whose peer
+ * died) is not complete after timeout_ms milliseconds (0: no bound). Nothing is cancelled: the caller decides (bench.py exits). */
+int gpuart_hip_wait(gpuart_hip_ctx *ctx, uint32_t timeout_ms);
 
 /* Execution mode of gpuart_hip_pt_pass / gpuart_hip_render_direct (images are identical, bit for bit, in all modes):
  *   0 (default) fast: the launch-per-stage wavefront pipeline (per segment a persistent BVH-query launch that also carries
@@ -197,6 +210,22 @@ int gpuart_hip_kernel_time(gpuart_hip_ctx *ctx, int cls, double *total_ms, uint6
 /* Scene statistics after upload: node count, primitive count, tree depth, device bytes. */
 int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims, uint32_t *max_depth,
                           uint64_t *device_bytes);
+
+/* ---- run planner test hook (pure host code: needs no device and no context) ------------------
+ * Drives the library's own run planner (csrc/hip/run_planner.h — the code gpuart_hip_resize / _set_share / _pt_plan /
+ * _set_mode / _pt_pass / _flush take their scheduling decisions from) through a sequence of operations and reports every
+ * pipeline run it would launch, so that a test can assert the invariants without a GPU: every run has 1 <= passes <=
+ * max_batch (a lane's path buffers hold n_slots x max_batch paths), stays within the path budget, and passes are launched in
+ * order, each exactly once.
+ *   cfg[8]  = { max_batch cap (1..64), pass lanes, batch Mpaths, min-run Kpaths, small Kpaths, lane budget MB,
+ *               plan-run percent, 0 }                       (0 in a field = the library's default)
+ *   ops     = n_ops triples (op, a, b):  0 RESIZE(width, height)   1 SHARE(rank, nranks) of the current frame, 8-row bands
+ *             2 PLAN(passes, -)   3 MODE(mode, -)   4 PASS(count, -) = count calls of pt_pass   5 FLUSH(-, -)
+ *             6 ALLOC_FAILS(n, -): the next RESIZE / SHARE finds the device refusing its first n allocation attempts
+ *   runs    = up to max_runs records of 6 words: { index of the op that launched it, n_slots, max_batch, passes of the run,
+ *             1 if it goes through k_run, passes still pending afterwards }
+ * Returns the number of runs (which may exceed max_runs: only the first max_runs are stored), or a negative error. */
+int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_ops, uint32_t *runs, int max_runs);
 
 /* ---- device-function test hooks (parity tests call the device code through these) ----------
  * Arrays are n x 4 float32 in host memory. Each mirrors one reference GLSL function. */

@@ -350,12 +350,17 @@ def test_deep_tree_frames(B, be, O):
     be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
     seeds = O.randseeds(2)
     acc = np.zeros((H, W, 4), np.float32)
-    be.pt_reset()
     for k in range(2):
-        be.pt_pass(to_params(B, P), seeds[k], 1)
         O.pt_pass(tree, c, W, H, P, seeds[k], 1, acc)
     assert (acc[..., :3].sum(-1) > 0).mean() > 0.5
-    assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "deep tree PT")
+    # default, launch pipeline, run kernel: a draining wave regroups its rays (thin-wave modes) with part of their stacks spilled
+    for mode in (0, 3, 5):
+        be.set_mode(mode)
+        be.pt_reset()
+        for k in range(2):
+            be.pt_pass(to_params(B, P), seeds[k], 1)
+        assert_bits(be.read(1)[..., :3].reshape(-1, 3), acc[..., :3].reshape(-1, 3), "deep tree PT, mode %d" % mode)
+    be.set_mode(0)
     be.render_direct(to_params(B, P))
     exp, _ = O.render_direct(tree, c, W, H, P)
     assert_bits(be.read(0)[..., :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "deep tree direct")
@@ -1025,10 +1030,11 @@ def test_headless_cli_resume_continues_to_more_paths(tmp_path):
 
 def test_rccl_gather_with_one_rank(B, be, O):
     """The gather of include/gpuart_hip.h on real RCCL, as far as one GPU allows: communicator of one rank (ncclGetUniqueId,
-    ncclCommInitRank through dlopen), share exchange (ncclAllGather), empty send/recv group, the root's export + row scatter
-    into a device frame — for a whole-frame share and for an interleaved share 1 of 3 (its rows land in their frame rows,
-    the rest of the frame stays untouched). The N > 1 transfers run on the driver's 8-GPU node; their host logic is covered
-    by tests/test_sharding_gloo.py."""
+    ncclCommInitRank through dlopen; ncclCommCount / ncclCommUserRank read back), exchange of share + status (ncclAllGather), empty
+    send/recv group, the root's export + row scatter into a device frame. Shares that do not cover every frame row exactly once
+    are refused on every rank BEFORE anything is transferred (a share 1 of 3 alone; an empty share alone), and an empty share
+    renders nothing without failing. The N > 1 transfers run on the driver's 8-GPU node; their host logic is covered by
+    tests/test_sharding_gloo.py."""
     import torch
     W, H = 72, 40
     cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
@@ -1037,12 +1043,16 @@ def test_rccl_gather_with_one_rank(B, be, O):
     sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
     P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
     be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    with pytest.raises(B.HipError):
+        be.comm_info()  # no communicator yet
     be.comm_init(1, 0, B.comm_unique_id())
     try:
-        for share in (B.share_of_rank(W, H, 0, 1), B.share_of_rank(W, H, 1, 3)):
+        assert be.comm_info() == (1, 0)
+        for bands in (8, 3):  # the whole frame as one share, in bands of 8 and of 3 rows
+            share = B.share_of_rank(W, H, 0, 1, bands)
             be.set_share(share)
             g = be.get_share()
-            assert (g.y0, g.th, g.band_stride) == (share.y0, share.th, share.band_stride)
+            assert (g.y0, g.th, g.band_rows, g.band_stride) == (0, H, bands, bands)
             be.pt_reset()
             for seed in O.randseeds(2):
                 be.pt_pass(to_params(B, P), seed, 1)
@@ -1050,15 +1060,34 @@ def test_rccl_gather_with_one_rank(B, be, O):
             full = torch.full((H, W, 4), -7.0, dtype=torch.float32, device="cuda:0")
             torch.cuda.synchronize()
             be.gather(1, 2.0, 0, full.data_ptr())
-            be.finish()
-            got = full.cpu().numpy()
-            rows = g.rows()
-            assert_bits(got[rows].reshape(-1, 4), tile.reshape(-1, 4), "gathered rows")
-            rest = np.setdiff1d(np.arange(H), rows)
-            assert (got[rest] == -7.0).all()
+            be.wait(30000)
+            assert_bits(full.cpu().numpy().reshape(-1, 4), tile.reshape(-1, 4), "gathered rows")
+        full = torch.full((H, W, 4), -7.0, dtype=torch.float32, device="cuda:0")
+        # a share that leaves rows to nobody: refused, nothing written
+        be.set_share(B.share_of_rank(W, H, 1, 3))
+        be.pt_reset()
+        be.pt_pass(to_params(B, P), O.randseeds(1)[0], 1)
+        with pytest.raises(B.HipError, match="belongs to no rank"):
+            be.gather(1, 1.0, 0, full.data_ptr())
+        be.finish()
+        # the root without a frame buffer: its own verdict travels with its share, the call fails instead of hanging
+        be.set_share(B.share_of_rank(W, H, 0, 1))
+        with pytest.raises(B.HipError, match="frame buffer"):
+            be.gather(1, 1.0, 0, 0)
+        # an empty share (more ranks than bands): rendering is a no-op, the context stays usable
+        be.resize(W, 8)
+        be.set_share(B.share_of_rank(W, 8, 1, 2))
+        assert be.get_share().th == 0
+        be.pt_reset()
+        be.pt_pass(to_params(B, P), O.randseeds(1)[0], 1)
+        be.render_direct(to_params(B, P))
+        be.finish()
+        with pytest.raises(B.HipError, match="belongs to no rank"):
+            be.gather(1, 1.0, 0, full.data_ptr())
+        assert (full.cpu().numpy() == -7.0).all()
     finally:
         be.comm_destroy()
-        be.set_tile(0, 0, W, H)
+        be.resize(W, H)
 
 
 def test_headless_cli_gather_path(tmp_path):
@@ -1074,3 +1103,81 @@ def test_headless_cli_gather_path(tmp_path):
     out = subprocess.run(base + ["--pfm", b], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stderr
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+# ---- row N1 of SURVEY 8(f): the product's own loaders and scenes, on the GPU ------------------------------------------
+def _loader_case(name, tmp_path):
+    """(renderer.init_*(file written for it), camera selector) for a frames_<name>*.npz fixture."""
+    if name == "cluster":
+        path = str(tmp_path / "cluster_100k.dat"); S.write_lines(path, S.cluster_dat_lines())
+        return (lambda r: r.init_cluster(path))
+    if name == "tree":
+        path = str(tmp_path / "tree1_21k.dat"); S.write_lines(path, S.tree_dat_lines())
+        return (lambda r: r.init_tree(path))
+    path = str(tmp_path / "dragon_stand_in.ply")
+    model, faces = S.dragon_class_mesh()
+    S.write_ply(path, model, faces)
+    return (lambda r: r.init_dragon(path))
+
+
+@pytest.mark.parametrize("fixture", ["frames_cluster_seg5", "frames_cluster_near_seg5", "frames_tree_seg5", "frames_tree_near_seg5", "frames_scene_d_seg5"])
+def test_scenes_through_the_products_loaders_equal_the_reference_frames(B, fixture, tmp_path):
+    """InitCluster / InitTree / InitDragon (csrc/host/scenes.cpp: file -> Utils::LoadPrimitives / LoadMeshFromPLY -> SetPrimitives ->
+    BVH build, compile, upload) on the seeded stand-ins of the absent data files, rendered through the Renderer; direct lighting
+    and the accumulated passes equal the frames the reference's GLSL produced on llvmpipe for the same scenes, bit for bit."""
+    g = golden(fixture)
+    name = str(g["scene"])
+    W, H = int(g["W"]), int(g["H"])
+    near = "_near" in fixture
+    cam = dict(S.NEAR_CAMERAS[name] if near else S.BENCH_CAMERA if name == "scene_d" else S.DEFAULT_CAMERA)  # as make_golden.py chose them
+    cam["dir"] = S.camera_dir(cam)
+    init = _loader_case(name, tmp_path)
+    r = B.Renderer(W, H, cam)
+    try:
+        r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+        assert init(r) and r.is_ok()
+        r.set_max_path_segments(int(g["max_segments"]))
+        r.render_direct()
+        check_frame(r.read_direct(), g["direct"], fixture + " direct")
+        if "direct_nosun" in g:
+            r.set_sun(S.SUN_AZIMUTH, S.SUN_ALTITUDE, direct=False)
+            r.render_direct()
+            check_frame(r.read_direct(), g["direct_nosun"], fixture + " direct, Sun off")
+            r.set_sun(S.SUN_AZIMUTH, S.SUN_ALTITUDE, direct=True)
+        r.set_seed(5489)
+        r.restart_path_tracing(1, 2)
+        assert r.path_tracing_pass() == 1
+        check_frame(r.read_radiance(False), g["pt_pass1"], fixture + " pass 1")
+        assert r.path_tracing_pass() == 2
+        check_frame(r.read_radiance(False), g["pt_acc"], fixture + " accumulated")
+        if "pt_3paths" in g:
+            r.set_seed(5489)
+            r.restart_path_tracing(3, 3)
+            assert r.path_tracing_pass() == 3
+            check_frame(r.read_radiance(False), g["pt_3paths"], fixture + " 3 paths per pass")
+    finally:
+        r.close()
+
+
+def test_the_run_shape_that_faulted_in_round_2(B, be, O, dragon_1080p):
+    """1080p, a plan of 20 passes, ten passes + flush, twice (gpurun_out/k20_plans.txt of round 2: a 10-pass run handed to lanes
+    that hold 8 passes read past the path buffers). The planner (csrc/hip/run_planner.h, tests/test_run_planner.py) splits such a
+    flush; the frame equals the oracle in a window, in the default mode and with k_run forced."""
+    W, H, c, tree, P = dragon_1080p
+    seeds = O.randseeds(20)
+    x0, y0 = W // 2 - 32, H // 2
+    exp = np.zeros((8, 64, 4), np.float32)
+    for sd in seeds:
+        O.pt_pass(tree, c, W, H, P, sd, 1, exp, tile=(x0, y0, 64, 8), nthreads=4)
+    be.resize(W, H); be.upload_bvh(tree); be.set_camera(c)
+    for mode in (0, 5):
+        be.set_mode(mode)
+        be.pt_reset()
+        be.pt_plan(20)
+        for half in range(2):
+            for k in range(10):
+                be.pt_pass(to_params(B, P), seeds[10 * half + k], 1)
+            be.flush()
+        acc = be.read(1)
+        assert_bits(acc[y0:y0 + 8, x0:x0 + 64, :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "20 passes as 10 + 10, mode %d" % mode)
+    be.set_mode(0)

@@ -22,6 +22,13 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), "libgpuart_hip.so does not export " + n
+    # ... and nothing else: a host program that defines `launch_run` or `check_shares` of its own must not be interposed
+    # (the link uses csrc/hip/exports.map)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", B.hip_lib()._name], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    extra = [n for n in exported if n not in names]
+    assert not extra, "libgpuart_hip.so exports symbols the header does not declare: %s" % extra
 
 
 def test_host_c_api_exports():

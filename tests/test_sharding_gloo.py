@@ -1,4 +1,4 @@
-"""CPU tests of the multi-rank host logic: band partition + gather over torch.distributed/gloo, world size 2 and 3."""
+"""CPU tests of the multi-rank host logic: the share layout + the host form of the gather over torch.distributed/gloo, world size 2 and 3."""
 import os
 import socket
 
@@ -9,20 +9,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from gpuart_amd import sharding
-
-
-def test_balanced_bands_properties():
-    rng = np.random.RandomState(0)
-    for world in (1, 2, 3, 4, 8):
-        for height in (64, 1080, 2160, 4320):
-            cost = rng.uniform(1, 10, height) * (np.arange(height) > height // 3)
-            bands = sharding.balanced_bands(world, height, cost)
-            assert len(bands) == world and bands[0][0] == 0 and sum(h for _, h in bands) == height
-            for (y0, h), (y1, _) in zip(bands, bands[1:] + [(height, 0)]):
-                assert h >= 8 and y0 + h == y1 and y0 % 8 == 0
-            if world > 1 and height >= 1080:
-                loads = [cost[y0:y0 + h].sum() for y0, h in bands]
-                assert max(loads) < 1.35 * (sum(loads) / world)
 
 
 def test_interleaved_rows_partition_the_frame():
@@ -70,16 +56,9 @@ def _worker(rank, world, port, H, W, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cost = np.where(np.arange(H) < H // 2, 1.0, 9.0) * W
-    bands = sharding.balanced_bands(world, H, cost)
-    y0, rows = bands[rank]
-    band = torch.from_numpy(_pixel_value(H, W)[y0:y0 + rows].copy())     # "this rank's rendered tile"
-    full = torch.zeros((H, W, 4)) if rank == 0 else None
-    dist.barrier()
-    out = sharding.gather_bands(dist, band, bands, rank, full)
-    dist.barrier()
-    # the interleaved shares bench.py and gpuart_cli --gpus use: the library's own layout + host scatter (the host half of gpuart_hip_gather), incl. a ragged last band
-    ok3 = True
+    # the interleaved shares bench.py and gpuart_cli --gpus use: the library's own layout + host scatter (the host half of
+    # gpuart_hip_gather), incl. a ragged last band and a frame with fewer bands than ranks (an empty share)
+    ok = True
     for (h3, w3) in ((H, W), (61, 37), (8, 5)):
         from gpuart_amd import binding as B
         g = B.share_of_rank(w3, h3, rank, world)
@@ -88,15 +67,14 @@ def _worker(rank, world, port, H, W, q):
         out3 = sharding.gather_shares_host(dist, mine, rank, world, w3, h3, full3)
         dist.barrier()
         if rank == 0:
-            ok3 = ok3 and bool((out3.numpy() == _pixel_value(h3, w3)).all())
+            ok = ok and bool((out3.numpy() == _pixel_value(h3, w3)).all())
     if rank == 0:
-        ok = bool((out.numpy() == _pixel_value(H, W)).all()) and ok3
-        q.put((bands, ok))
+        q.put(ok)
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_gather_bands_over_gloo(world):
+def test_gather_shares_over_gloo(world):
     H, W = 96, 40
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -104,9 +82,8 @@ def test_gather_bands_over_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q)) for r in range(world)]
     for p in procs:
         p.start()
-    bands, ok = q.get(timeout=120)
+    ok = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert ok and len(bands) == world
-    assert bands[0][1] > bands[-1][1]  # cheap rows get taller bands
+    assert ok
