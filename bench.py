@@ -70,11 +70,14 @@ VALU_SAME_MIX_GINSTR = 846.0    # the product's own box test on registers (87 VA
 LLVMPIPE_CONTAINER = {
     "cfg3": {"value": 0.957, "ms_per_frame": 5428.8},
     "cfg2": {"value": 3.315, "ms_per_frame": 1409.3},
+    "dragon871k": {"value": 0.737, "ms_per_frame": 7073.4},  # profiles/r03/llvmpipe_reference_glsl_container_871k.txt
 }
 
 WORKLOADS = {
     "cfg3": dict(text="Scene D (dragon-class, 100352 triangles + floor disc)", segs=8, camera="benchmark camera"),
     "cfg2": dict(text="Scene P (256 spheres + 16 discs)", segs=4, camera="default camera"),
+    "dragon871k": dict(text="the reference's largest scene at its size (src/main.cpp:321 \"dragon 871k\"): 871200-triangle stand-in + floor disc, "
+                            "75 MB of tree on the device (it leaves the L2s)", segs=8, camera="benchmark camera"),
     "cluster": dict(text="InitCluster on the synthetic cluster_100k stand-in (100000 spheres + floor disc)", segs=5, camera="near camera"),
     "tree": dict(text="InitTree on the synthetic tree1_21k stand-in (9841 cones + 9775 spheres + floor disc)", segs=5, camera="near camera"),
 }
@@ -90,7 +93,8 @@ def parse_args():
                          "the 4K frame north_star also asks for — see DESIGN.md for its numbers)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3",
                     help="cfg3 (default, the configuration the metric is quoted on): Scene D, depth 8; cfg2 of BASELINE.json: Scene P, "
-                         "depth 4; cluster / tree: the reference's two primitive-list scenes (InitCluster / InitTree) on seeded stand-ins")
+                         "depth 4; cluster / tree: the reference's two primitive-list scenes (InitCluster / InitTree) on seeded stand-ins; "
+                         "dragon871k: cfg3's workload on a mesh of the real Stanford dragon's size (the tree leaves the L2s)")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the K-pass timed sequence is run (median reported, min/max beside it)")
     ap.add_argument("--gather-timeout", type=float, default=120.0,
                     help="N > 1: seconds a rank waits for the frame gather before it names the ranks that have not arrived and exits non-zero")
@@ -118,13 +122,13 @@ def make_renderer(args, W, H, device, tmpdir):
     from gpuart_amd import binding as B
     from gpuart_amd import synth_scenes as S
     w = args.workload
-    cam = dict({"cfg3": S.BENCH_CAMERA, "cfg2": S.DEFAULT_CAMERA, "cluster": S.CLUSTER_NEAR_CAMERA, "tree": S.TREE_NEAR_CAMERA}[w])
+    cam = dict({"cfg3": S.BENCH_CAMERA, "dragon871k": S.BENCH_CAMERA, "cfg2": S.DEFAULT_CAMERA, "cluster": S.CLUSTER_NEAR_CAMERA, "tree": S.TREE_NEAR_CAMERA}[w])
     cam["dir"] = S.camera_dir(cam)
     t0 = time.time()
     r = B.Renderer(W, H, cam, device=device)
     r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
-    if w in ("cfg3", "cfg2"):
-        descs = S.scene_d() if w == "cfg3" else S.scene_p()
+    if w in ("cfg3", "cfg2", "dragon871k"):
+        descs = S.scene_d() if w == "cfg3" else S.scene_d(660, 660) if w == "dragon871k" else S.scene_p()
         r.set_primitives(B.make_prims(descs))
     else:  # through the reference's loader path: a .dat file, InitCluster / InitTree (src/scenes.cpp:69-103)
         lines = S.cluster_dat_lines() if w == "cluster" else S.tree_dat_lines()
@@ -156,6 +160,7 @@ def profile_children(args, K, Wm):
     env = dict(os.environ, TMPDIR="/tmp")
     for tag, counters in (("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES"]),
                           ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]),
+                          ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"]),
                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
         d = tempfile.mkdtemp(prefix="gpuart_pmc_", dir="/tmp")
         try:
@@ -483,6 +488,13 @@ def main():
             roof["achieved"] = round(acc / (ms_step * 1e-3) / 1e9, 2)
             roof["frac"] = round(roof["achieved"] / L1_PEAK_GACC, 4)
             roof["frac_of_one_access_per_clock"] = round(roof["achieved"] / 614.4, 4)
+            l2 = prof["tcc"][0]
+            if l2.get("TCC_REQ_sum"):
+                roof["l2"] = {"requests_per_pass": l2["TCC_REQ_sum"] / n, "hits_per_pass": l2.get("TCC_HIT_sum", 0.0) / n,
+                              "misses_per_pass": l2.get("TCC_MISS_sum", 0.0) / n,
+                              "hit_rate": round(l2.get("TCC_HIT_sum", 0.0) / max(1.0, l2.get("TCC_HIT_sum", 0.0) + l2.get("TCC_MISS_sum", 0.0)), 4),
+                              "note": "TCC_HIT / TCC_MISS / TCC_REQ summed over the L2 channels and all kernels of a pass; misses go on to the "
+                                      "Infinity Cache and HBM (`traffic`)"}
             # HBM traffic: FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B; calibrated for wide streams — our 16-B gathers
             # are uncalibrated, read it as an upper estimate), both counters in KB; counts Infinity-Cache hits too
             fetch = prof["fetch"][0].get("FETCH_SIZE", 0.0) / n
@@ -572,7 +584,7 @@ def main():
         "cpu_baseline_reference_glsl": None if glsl is None else {
             "value": glsl["value"], "unit": "Mrays/s", "cores": 8, "kind": "reference", "ms_per_frame": glsl["ms_per_frame"],
             "where": "BUILD CONTAINER (8 vCPU Xeon), not this box: the reference's unmodified GLSL on Mesa llvmpipe, same scene / camera / "
-                     "ray definition (tests/golden/time_llvmpipe.py; profiles/r02/llvmpipe_reference_glsl_container.txt)"},
+                     "ray definition (tests/golden/time_llvmpipe.py; profiles/r02/llvmpipe_reference_glsl_container.txt, profiles/r03/llvmpipe_reference_glsl_container_871k.txt)"},
     }
     print(json.dumps(out))
     r.close()

@@ -499,6 +499,7 @@ class RefRenderer:
 
 def scene_tree(name):
     prims = {"box": S.box_scene, "scene_p": S.scene_p, "scene_d": S.scene_d, "cluster": S.cluster_scene, "tree": S.tree_scene,
+             "dragon871k": lambda: S.scene_d(660, 660),
              "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64)}[name]()
     tree, depth = O.build_bvh(prims)
     return prims, tree, depth
@@ -726,7 +727,22 @@ def gen_cluster_tree(gl):
                  bvh_depth=depth, **out)
 
 
-SECTIONS = dict(scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
+def gen_dragon871k(gl):
+    """The reference's largest scene as a stand-in of its size (main.cpp:321 "dragon 871k": 871 200 triangles; here the displaced torus
+    at 660 x 660 quads + floor disc; 75 MB of tree on the device, which no longer fits the L2s): benchmark camera, depth 8,
+    direct lighting + two passes at 128x72 through the reference's shaders."""
+    seeds = O.randseeds(16)
+    _, tree, depth = scene_tree("dragon871k")
+    progs = RefPrograms(gl, 8)
+    r = RefRenderer(gl, progs, 128, 72, default_cam(S.BENCH_CAMERA), tree)
+    out = {"direct": r.direct()[..., :3].copy()}
+    r.reset()
+    out["pt_pass1"] = r.pt_pass(1, seeds[0])[..., :3].copy()
+    out["pt_acc"] = r.pt_pass(1, seeds[1])[..., :3].copy()
+    save("frames_dragon871k_seg8", scene="dragon871k", W=128, H=72, cam=r.cam, max_segments=8, npasses=2, seeds=seeds, bvh_depth=depth, **out)
+
+
+SECTIONS = dict(dragon871k=gen_dragon871k, scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
                 disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 

@@ -34,7 +34,7 @@ if not glref.available():
 gl = glref.GLRef()
 W, H = a.width, a.height
 _, tree, _ = MG.scene_tree(a.scene)
-cam = MG.default_cam(S.BENCH_CAMERA if a.scene == "scene_d" else S.DEFAULT_CAMERA)
+cam = MG.default_cam(S.BENCH_CAMERA if a.scene in ("scene_d", "dragon871k") else S.DEFAULT_CAMERA)
 r = MG.RefRenderer(gl, MG.RefPrograms(gl, a.max_segments), W, H, cam, tree)
 seeds = O.randseeds(a.passes + 1)
 r.direct()

@@ -1181,3 +1181,35 @@ def test_the_run_shape_that_faulted_in_round_2(B, be, O, dragon_1080p):
         acc = be.read(1)
         assert_bits(acc[y0:y0 + 8, x0:x0 + 64, :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "20 passes as 10 + 10, mode %d" % mode)
     be.set_mode(0)
+
+
+def test_dragon871k_window_at_1080p(B, O):
+    """The reference's largest scene at its size (src/main.cpp:321 "dragon 871k"; here the 871 200-triangle stand-in + floor disc,
+    75 MB of tree — it no longer fits the L2s) through Renderer::SetPrimitives at BASELINE's frame size: two progressive passes,
+    an oracle window in the middle of the mesh, whole-frame sanity. (The same tree at 128x72 against the reference's GLSL:
+    frames_dragon871k_seg8 in test_frames_vs_reference_goldens.)"""
+    W, H = 1920, 1080
+    cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
+    descs = scene("dragon871k")
+    r = B.Renderer(W, H, cam)
+    try:
+        r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+        r.set_primitives(B.make_prims(descs))
+        assert r.is_ok() and r.backend.scene_info()["prims"] == 871201
+        r.set_max_path_segments(8)
+        r.restart_path_tracing(1, 2)
+        assert [r.path_tracing_pass() for _ in range(2)] == [1, 2]
+        acc = r.read_radiance(False)
+    finally:
+        r.close()
+    assert np.isfinite(acc[..., :3]).all() and acc[..., :3].min() >= 0
+    tree, _ = O.build_bvh(descs)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 8, 0.01)
+    x0, y0 = W // 2 - 32, H // 2
+    exp = np.zeros((16, 64, 4), np.float32)
+    for sd in O.randseeds(2):
+        O.pt_pass(tree, c, W, H, P, sd, 1, exp, tile=(x0, y0, 64, 16), nthreads=4)
+    assert (exp[..., :3].sum(-1) > 0).mean() > 0.5
+    assert_bits(acc[y0:y0 + 16, x0:x0 + 64, :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "871k-triangle scene, 1080p window")

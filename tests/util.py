@@ -25,6 +25,7 @@ SCENES = {
     "scene_d": S.scene_d,
     "cluster": S.cluster_scene,
     "tree": S.tree_scene,
+    "dragon871k": lambda: S.scene_d(660, 660),
     "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64),
 }
 

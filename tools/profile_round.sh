@@ -14,16 +14,17 @@ cp $OUT/trace/x_kernel_stats.csv $OUT/kernel_stats.csv
 python3 tools/trace_agreement.py $OUT/trace/x_kernel_trace.csv $OUT/trace.log > $OUT/trace_vs_events.txt
 rm -rf $OUT/trace
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-for w in cfg2 cluster tree; do timeout -k 10 400 python3 bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
+for w in cfg2 cluster tree dragon871k; do timeout -k 10 400 python3 bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
 timeout -k 10 400 python3 bench.py --frame 3840x2160 --steps 16 --warmup 4 > $OUT/bench_4k.json 2> $OUT/bench_4k.err
 timeout -k 10 400 python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile > $OUT/bench_steps1.json 2> $OUT/bench_steps1.err
 python3 tools/tile_overhead.py > $OUT/tile_scaling_one_gpu.txt 2>&1
+TILE_K=20 python3 tools/tile_overhead.py > $OUT/tile_scaling_one_gpu_k20.txt 2>&1
 python3 tools/time_direct.py > $OUT/direct_lighting.txt 2>&1
 (python3 tools/bvh_build_time.py scene_d; python3 tools/bvh_build_time.py big; for s in scene_d big cluster tree; do python3 tools/setprims_time.py $s; done) > $OUT/bvh_build.txt 2>&1
 timeout -k 10 200 tools/ubench/ubench > $OUT/ubench.txt 2>&1
 python3 - <<PY
 import json
-for f in ["bench", "bench_cfg2", "bench_cluster", "bench_tree", "bench_4k", "bench_steps1"]:
+for f in ["bench", "bench_cfg2", "bench_cluster", "bench_tree", "bench_dragon871k", "bench_4k", "bench_steps1"]:
     d = json.loads(open("$OUT/%s.json" % f).read().strip().split("\n")[-1])
     r = d["roofline"]
     print("%-14s %8.1f Mrays/s (executed %8.1f)  %.4f ms/step  single %s  L1 frac %s  valu frac %s  lane_util %s  traffic_frac %s  cpu %s" % (
