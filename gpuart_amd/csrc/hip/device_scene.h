@@ -487,6 +487,19 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
     }
     if (hit) trav_enter(t, sc.root_ref, entry);  // entry > 1e19 cannot happen
     else t.state = TRAV_DONE;
+#ifdef GD_ROOT_PROBE
+    // Measurement hook (never in the product build): what the fetch of the root's record costs a ray — every lane that starts a
+    // query fetches record 0 once more (same address in all lanes, as the real fetch of that record is). Passing the record in
+    // kernel arguments instead could at best save this much; built for real (the visit of the root fused into this function,
+    // record from scalar loads) it LOST 1.6-3.5 %: the fused visit is issued for the few lanes that start a query, beside the
+    // wave's regular box step (profiles/r03/request_trims.txt).
+    for (int k = 0; k < GD_ROOT_PROBE; k++) {
+        const float4 *rp = sc.recs;
+        asm volatile("" : "+v"(rp));
+        float4 d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
+        asm volatile("" ::"v"(d0.x), "v"(d0.w), "v"(d1.x), "v"(d1.w), "v"(d2.x), "v"(d2.z), "v"(d3.x), "v"(d3.z));
+    }
+#endif
 }
 
 /// One interior-node visit: fetch its record, test both children's boxes, descend / stack / pop.
@@ -677,6 +690,17 @@ GD_FN void traverse(const Scene &sc, const Ray &r, TravStack &st, float &closest
 /// Recomputes point, normal and type of the winning primitive (pure function of ray + record).
 GD_FN void shade_prim(const Scene &sc, const Ray &r, uint32_t pi, Surface &s) {
     float4 q0 = sc.prims[3 * pi], q1 = sc.prims[3 * pi + 1], q2 = sc.prims[3 * pi + 2];
+#ifdef GD_SHADE_PROBE
+    // Measurement hook (never in the product build): the hit primitive's three quads are fetched GD_SHADE_PROBE more times — what
+    // carrying them over from the query instead of re-fetching them could at best save: nothing measurable
+    // (profiles/r03/request_trims.txt)
+    for (int k = 0; k < GD_SHADE_PROBE; k++) {
+        const float4 *rp = sc.prims + 3 * (size_t)pi;
+        asm volatile("" : "+v"(rp));
+        float4 d0 = rp[0], d1 = rp[1], d2 = rp[2];
+        asm volatile("" ::"v"(d0.x), "v"(d0.w), "v"(d1.x), "v"(d1.w), "v"(d2.x), "v"(d2.w));
+    }
+#endif
     prim_hit(r, q0, q1, q2, s.pos, s.p, s.n, s.ptype);
 }
 
