@@ -102,7 +102,6 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     const uint32_t total = b.n_slots * b.batch;  // a multiple of 64: one chunk = 64 consecutive path slots (few pixels x the run's passes)
     const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
-    const unsigned long long below = (1ull << lane_id()) - 1;
     WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t segments = 0;
 
@@ -112,12 +111,11 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     const uint32_t static_end = gridDim.x * BLOCK;  // the first chunk of every wave is static, the cursor starts behind them
 
     // Thin-wave modes (tail only): M lanes per ray, rays at lanes [M q, M q + M) as identical replicas; `lead` = the first lane of
-    // every group, `sub` = this lane's index in its group, `below` then counts the groups before this lane's. Never entered by the
+    // every group, `sub` = this lane's index in its group. Never entered by the
     // counting variants (their counters are per lane) and by trees with irregular boxes (comparison-form box tests).
     constexpr bool THIN_OK = RUN_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
     uint32_t M = 1, sub = 0;                                   // M wave-uniform
     unsigned long long lead = ~0ull;                           // wave-uniform
-    unsigned long long below_g = below;                        // the lanes before this lane's group
     __shared__ uint32_t xfer[BLOCK];
 
     // per-lane query state
@@ -166,7 +164,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 if (joins) to_shade = atomicSub(&b.queue[0][s], 1u) == 1u;
             }
             const unsigned long long m = __ballot(to_shade);
-            if (to_shade) shadeq[n_shade + (uint32_t)__popcll(m & below)] = ent & (RUN_SLOT | RUN_F_FRESH);
+            if (to_shade) shadeq[n_shade + rank_below(m)] = ent & (RUN_SLOT | RUN_F_FRESH);
             n_shade += (uint32_t)__popcll(m);
             n_live -= (uint32_t)__popcll(__ballot(ended));
             if (ent != SLOT_INVALID && t.state == TRAV_DONE) ent = SLOT_INVALID;
@@ -237,10 +235,10 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 // oldest first: the short shadow queries of a batch go before its closest-hit queries
                 n_live -= (uint32_t)__popcll(__ballot(ended));
                 unsigned long long m = __ballot(out_sh != SLOT_INVALID);
-                if (out_sh != SLOT_INVALID) ready[(r_head + n_ready + (uint32_t)__popcll(m & below)) & (RUN_RQ - 1)] = out_sh;
+                if (out_sh != SLOT_INVALID) ready[(r_head + n_ready + rank_below(m)) & (RUN_RQ - 1)] = out_sh;
                 n_ready += (uint32_t)__popcll(m);
                 m = __ballot(out != SLOT_INVALID);
-                if (out != SLOT_INVALID) ready[(r_head + n_ready + (uint32_t)__popcll(m & below)) & (RUN_RQ - 1)] = out;
+                if (out != SLOT_INVALID) ready[(r_head + n_ready + rank_below(m)) & (RUN_RQ - 1)] = out;
                 n_ready += (uint32_t)__popcll(m);
                 continue;
             }
@@ -280,7 +278,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 }
             }
             const unsigned long long m = __ballot(out != SLOT_INVALID);
-            if (out != SLOT_INVALID) ready[(r_head + n_ready + (uint32_t)__popcll(m & below)) & (RUN_RQ - 1)] = out;
+            if (out != SLOT_INVALID) ready[(r_head + n_ready + rank_below(m)) & (RUN_RQ - 1)] = out;
             n_ready += (uint32_t)__popcll(m);
             n_live += (uint32_t)__popcll(m);
         }
@@ -300,7 +298,6 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
                 sub = (uint32_t)lane_id() & (M - 1);
                 lead = M == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
-                below_g = (1ull << ((uint32_t)lane_id() & ~(M - 1))) - 1;
             }
         }
 
@@ -309,7 +306,8 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // rays / lists written by other lanes of this wave
             const unsigned long long idle = __ballot(ent == SLOT_INVALID) & lead;
             const uint32_t take = min((uint32_t)__popcll(idle), n_ready);
-            const uint32_t rank = (uint32_t)__popcll(idle & below_g);  // the same for every replica of a group
+            // `idle` holds the first lanes of the idle groups: a replica further back in such a group counts its own first lane too
+            const uint32_t rank = rank_below(idle) - (sub != 0 ? 1u : 0u);  // the same for every replica of a group
             if (ent == SLOT_INVALID && rank < take) {
                 ent = ready[(r_head + rank) & (RUN_RQ - 1)];  // oldest first: with paths generated ahead, the youngest segments go first
                 ro = xyz(b.ray_o[ent & RUN_SLOT]);

@@ -59,6 +59,8 @@ struct SeedBatch {
 #define SLOT_INVALID 0xffffffffu
 
 GD_FN int lane_id() { return threadIdx.x & 63; }
+/// Set bits of a ballot below this lane (v_mbcnt: no 64-bit lane mask to keep in registers).
+GD_FN uint32_t rank_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 /// Pass (index into the run's RandSeed batch / colour planes) and pixel slot of a path slot.
 GD_FN uint32_t slot_pass(const PathBuffers &b, uint32_t slot) { return slot % b.batch; }

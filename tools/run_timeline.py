@@ -48,6 +48,16 @@ for name, col, rc in (("pairs", 12, 14), ("quads", 13, 15)):
     sel = buf[:, col] > 0
     if sel.any():
         print("to %s     " % name, q(us(buf[sel, col])), " (%d waves; rounds in that mode, median %d)" % (int(sel.sum()), int(np.median(buf[sel, rc]))))
+sel = (buf[:, 13] > 0) & (end >= np.percentile(end, 95))
+if sel.any():
+    dq = (end[sel] - us(buf[sel, 13])); rq = buf[sel, 15].astype(np.float64)
+    print("the last 5 %% of the waves to end (%d): %.0f us in quad mode (median), %d rounds there, %.2f us per round (retire / shade episodes included)"
+          % (int(sel.sum()), np.median(dq), int(np.median(rq)), float(dq.sum() / max(1.0, rq.sum()))))
+sel = (buf[:, 13] > 0) & (end <= np.percentile(end, 30))
+if sel.any():
+    dq = (end[sel] - us(buf[sel, 13])); rq = buf[sel, 15].astype(np.float64)
+    print("the first 30 %% of the waves to end (%d): %.0f us in quad mode (median), %d rounds there, %.2f us per round"
+          % (int(sel.sum()), np.median(dq), int(np.median(rq)), float(dq.sum() / max(1.0, rq.sum()))))
 print("ready / shade list lengths summed over the rounds before the cursor ran dry / all rounds (lower bound of the mean): %.1f / %.1f" % (buf[:, 6].sum() / buf[:, 4].sum(), buf[:, 7].sum() / buf[:, 4].sum()))
 tt, to, tr, tg = [buf[:, k].astype(np.float64) for k in (8, 9, 10, 11)]
 print("after the cursor ran dry, per wave (medians): %.0f us in traversal rounds (%d rounds, %.2f us each), %.0f us in retire / shade / refill (%d times, %.2f us each)" % (
