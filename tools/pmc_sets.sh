@@ -1,6 +1,8 @@
 # Collects SQ / TCP / TCC counters of the bench workload in separate rocprofv3 --pmc passes (one small set per pass:
 # a set that asks for more than the hardware can collect at once aborts the profiler), keeping only counters the box
-# offers. (TA_* and TCP_GATE/STALL counters made the profiler hang on this pool: not asked for.)
+# offers. TA_* and TCP_GATE / TCP_*_STALL counters are not asked for: rocprofiler refuses them on gfx950 ("error code 38: Request exceeds
+# the capabilities of the hardware to collect", even one at a time), aborts with signal 6 and then sits in its own signal handler until
+# the timeout below kills it — the tool stalls, no kernel ever runs (profiles/r03/pmc_ta_tcp_sets_abort.txt).
 #   bash tools/pmc_sets.sh <tag> [passes]     -> gpurun_out/pmc_<tag>/s<i>/..., summary in gpurun_out/pmc_<tag>.txt
 R=$GRAFT_REPO_ROOT; TAG=${1:-x}; K=${2:-8}
 cd /tmp && export TMPDIR=/tmp
