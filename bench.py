@@ -344,7 +344,23 @@ def main():
     run_passes(r, Wm)
     be.finish()
     if dist is not None:
-        gather(float(max(1, Wm)))  # warm the exchange path too: the first transfer between two ranks sets up their channel
+        # warm the exchange path too (the first transfer between two ranks sets up their channel) — and make sure it works on every
+        # rank before anything is timed: an error of the library's gather on any rank moves ALL ranks to the announced fallback
+        # (a timeout cannot be recovered from: that rank has already named the missing ranks and exited)
+        failed = None
+        try:
+            gather(float(max(1, Wm)))
+        except B.HipError as e:
+            failed = str(e)
+        ok = torch.tensor([0 if failed else 1], dtype=torch.int32, device=xdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0 and gather_note is None:
+            gather_note = "gpuart_hip_gather failed in the warm-up (%s): gathered through torch.distributed point-to-point instead" % (failed or "on another rank")
+            try:
+                be.comm_destroy()
+            except B.HipError:
+                pass
+            gather(float(max(1, Wm)))
     be.set_timing(2)
     be.kernel_time(0, reset=True)
     be.kernel_time(1, reset=True)
