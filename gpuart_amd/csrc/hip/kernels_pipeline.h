@@ -110,12 +110,13 @@ GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t 
 /// every mode. Groups beyond the rays in flight come out idle (state DONE, empty stack; their tags are the caller's to reset).
 /// `xfer`: 64 words of LDS scratch.
 GD_FN void thin_regroup(uint32_t to, unsigned long long flying, uint32_t *xfer, uint2 *ring_a, float *ring_b, uint4 *spill,
-                        uint32_t &tag0, uint32_t &tag1, F3 &ro, F3 &rd, F3 &rdiv, Trav &t, TravStack &st) {
+                        uint32_t &tag0, uint32_t &tag1, F3 &ro, F3 &rd, F3 &rdiv, Trav &t, TravStack &st, int *src_lane = nullptr) {
     if ((flying >> lane_id()) & 1ull) xfer[__popcll(flying & ((1ull << lane_id()) - 1))] = (uint32_t)lane_id();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const uint32_t q = (uint32_t)lane_id() / to;
     const bool holds = q < (uint32_t)__popcll(flying);
     const int src = holds ? (int)xfer[q] : lane_id();
+    if (src_lane) *src_lane = src;  // for whatever else the caller keeps per ray
     tag0 = __shfl(tag0, src, 64); tag1 = __shfl(tag1, src, 64);
     ro = f3(__shfl(ro.x, src, 64), __shfl(ro.y, src, 64), __shfl(ro.z, src, 64));
     rd = f3(__shfl(rd.x, src, 64), __shfl(rd.y, src, 64), __shfl(rd.z, src, 64));
@@ -493,6 +494,10 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
+    // thin-wave modes (device_scene.h) for the end of the frame: once the pixel cursor is dry and the wave is down to 32 (16)
+    // pixels, pairs (quads) of lanes carry them
+    constexpr bool THIN_OK = GD_TRACE_THIN > 1 && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    uint32_t M = 1, sub = 0;  // M wave-uniform
     const float AMBIENT = 0.15f;
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
     const F3 usc = f3(P.userSphere[0], P.userSphere[1], P.userSphere[2]);
@@ -544,10 +549,55 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
             idle = __ballot(pixel == SLOT_INVALID);
             if (take == want) break;
         }
-        if (__ballot(pixel != SLOT_INVALID) == 0) {
+        const unsigned long long flying = __ballot(pixel != SLOT_INVALID && sub == 0);
+        if (flying == 0) {
             if (exhausted) break;
             continue;
         }
+        if (THIN_OK && exhausted && M < (uint32_t)GD_TRACE_THIN) {
+            const uint32_t left = (uint32_t)__popcll(flying);
+            const uint32_t to = left <= BLOCK / 4 && GD_TRACE_THIN >= 4 ? 4u : left <= BLOCK / 2 ? 2u : 1u;
+            if (to > M) {
+                __shared__ uint32_t xfer[BLOCK];
+                uint32_t tag = (uint32_t)stage | ((uint32_t)bounce << 8);
+                int src = lane_id();
+                thin_regroup(to, flying, xfer, ring_a, ring_b, spill, pixel, tag, ro, rd, rdiv, t, st, &src);
+                stage = (int)(tag & 255u); bounce = (int)(tag >> 8);
+                // the pixel's pending terms travel with it
+                auto move3 = [&](F3 &v) { v = f3(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)); };
+                move3(cw); move3(acc); move3(sun_term); move3(em_term); move3(em_dir); move3(ambient);
+                em_dist = __shfl(em_dist, src, 64);
+                if ((uint32_t)lane_id() / to >= left) pixel = SLOT_INVALID;
+                M = to;
+                sub = (uint32_t)lane_id() & (M - 1);
+            }
+        }
+        if (THIN_OK && M > 1) {
+            // the loop below with M lanes per pixel (the cursor is dry: pixels only ever finish)
+            auto thin_rounds = [&](auto width) {
+                constexpr int W = decltype(width)::value;
+                constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
+                for (;;) {
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
+                    unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
+                    const uint32_t waiting = (uint32_t)__popcll(at_leaf);
+                    if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
+                        if (t.state & 1) {
+                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+                            if (stage == DL_SUN && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;  // only "anything hit?" is asked
+                        }
+                        busy = __ballot(t.state != TRAV_DONE) & LEAD;
+                    }
+                    if (!busy) break;
+                    // lanes with an answer move their pixel on (the others stand still meanwhile): once they are a fair share of the wave
+                    const uint32_t answered = (uint32_t)__popcll(__ballot(pixel != SLOT_INVALID && t.state == TRAV_DONE) & LEAD);
+                    if (2 * answered >= (uint32_t)__popcll(busy)) break;
+                }
+            };
+            if (M == 2) thin_rounds(std::integral_constant<int, 2>());
+            else thin_rounds(std::integral_constant<int, 4>());
+        } else
         // ---- traverse until enough lanes have an answer (a lane without a pixel is in state DONE)
         for (;;) {
             if (t.state == TRAV_DESCEND) trav_step_box<false, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, nullptr);
@@ -566,7 +616,8 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
             if (!busy) break;
             if (64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
         }
-        // ---- lanes with an answer move their pixel on (direct_lighting.glsl:134-207)
+        // ---- lanes with an answer move their pixel on (direct_lighting.glsl:134-207); replicas do so identically (the one store
+        //      of a finished pixel is the same value to the same address)
         if (pixel != SLOT_INVALID && t.state == TRAV_DONE) {
             bool finished = false;
             if (stage == DL_PRIMARY) {
