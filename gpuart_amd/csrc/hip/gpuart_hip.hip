@@ -1295,11 +1295,11 @@ int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
 }
 
 #ifdef GD_RUN_TIMELINE
-/// diagnostic builds only: the per-wave timeline of the last k_run launch (kernel_run.h), 16 words per wave
+/// diagnostic builds only: the per-wave timeline of the last k_run launch (kernel_run.h), 24 words per wave
 int gpuart_hip_debug_run_timeline(gpuart_hip_ctx *c, unsigned long long *out, size_t waves) {
     if (!c || !out || waves > 8192) return GPUART_HIP_ERR_ARG;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_timeline), waves * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_timeline), waves * 24 * sizeof(unsigned long long)));
     return 0;
 }
 /// diagnostic builds only: reads (and clears) the busy-lane histogram of the k_run launches since the last call, 256 words

@@ -66,7 +66,7 @@
 #ifdef GD_RUN_TIMELINE
 // diagnostic build (tools/run_timeline.py): per wave, the 100 MHz clock at its start, when the cursor ran dry, at its end,
 // and the lane-rounds it spent traversing (active lanes summed over the rounds of the TRAVERSE loop / rounds)
-__device__ unsigned long long g_run_timeline[16 * 8192];
+__device__ unsigned long long g_run_timeline[24 * 8192];
 __device__ unsigned long long g_run_hist[2 * 128];  // busy lane-time and wave-time per 25 us bucket
 #endif
 
@@ -127,6 +127,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start, tl_nready = 0, tl_nshade = 0;
     unsigned long long tl_tail_trav = 0, tl_tail_other = 0, tl_tail_rounds = 0, tl_tail_trig = 0, tl_mark = tl_start;
     unsigned long long tl_m2 = 0, tl_m4 = 0, tl_r2 = 0, tl_r4 = 0;  // when the wave went to pairs / quads, rounds in either mode
+    unsigned long long tp_box = 0, tp_nbox = 0, tp_leaf = 0, tp_nleaf = 0, tp_loop = 0, tp_busy = 0;  // shader-clock cycles of the quad rounds: box steps, leaf steps, whole rounds
     __shared__ unsigned tl_hist[2 * 128];
     tl_hist[lane_id()] = 0; tl_hist[64 + lane_id()] = 0; tl_hist[128 + lane_id()] = 0; tl_hist[192 + lane_id()] = 0;
     const unsigned long long tl_zero = g_run_hist[2 * 128 - 1];  // the host stores the launch's reference clock there (0: use own start)
@@ -333,17 +334,34 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
+#ifdef GD_RUN_TIMELINE
+                    const unsigned long long pc0 = __builtin_amdgcn_s_memtime();
+                    if (__ballot(t.state == TRAV_DESCEND)) {
+                        if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                        if (W == 4) { tp_box += __builtin_amdgcn_s_memtime() - pc0; tp_nbox++; }
+                    }
+#else
                     if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+#endif
                     unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
                     if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
+#ifdef GD_RUN_TIMELINE
+                        const unsigned long long pl0 = __builtin_amdgcn_s_memtime();
+#endif
                         if (t.state & 1) {
                             trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
                             if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                         }
                         busy = __ballot(t.state != TRAV_DONE) & LEAD;
+#ifdef GD_RUN_TIMELINE
+                        if (W == 4) { tp_leaf += __builtin_amdgcn_s_memtime() - pl0; tp_nleaf++; }
+#endif
                     }
+#ifdef GD_RUN_TIMELINE
+                    if (W == 4) { tp_loop += __builtin_amdgcn_s_memtime() - pc0; tp_busy += (uint32_t)__popcll(busy); }
+#endif
                     GD_RUN_TL_ROUND((uint32_t)__popcll(busy))
                     if (!busy) break;
                     if ((uint32_t)BLOCK - W * (uint32_t)__popcll(busy) >= tune.refill_lanes) {
@@ -388,8 +406,9 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     if (COUNT) flush_counters(wc, segments, gcounters);
 #ifdef GD_RUN_TIMELINE
     if (lane_id() == 0 && blockIdx.x < 8192) {
-        unsigned long long *o = g_run_timeline + 16 * blockIdx.x;
+        unsigned long long *o = g_run_timeline + 24 * blockIdx.x;
         o[12] = tl_m2; o[13] = tl_m4; o[14] = tl_r2; o[15] = tl_r4;
+        o[16] = tp_box; o[17] = tp_nbox; o[18] = tp_leaf; o[19] = tp_nleaf; o[20] = tp_loop; o[21] = tp_busy; o[22] = 0; o[23] = 0;
         o[6] = tl_nready; o[7] = tl_nshade; o[8] = tl_tail_trav; o[9] = tl_tail_other; o[10] = tl_tail_rounds; o[11] = tl_tail_trig;
         o[0] = tl_start; o[1] = tl_dry; o[2] = wall_clock64(); o[3] = tl_lanes; o[4] = tl_rounds;
         for (int k = 0; k < 256; k++) if (tl_hist[k]) atomicAdd(&g_run_hist[k], (unsigned long long)tl_hist[k]);

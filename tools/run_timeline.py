@@ -30,7 +30,7 @@ for it in range(3):
         r.path_tracing_pass()
     r.finish()
 n = 4096
-buf = np.zeros((n, 16), np.uint64)
+buf = np.zeros((n, 24), np.uint64)
 L.gpuart_hip_debug_run_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = L.gpuart_hip_debug_run_timeline(r.backend.ctx, buf.ctypes.data_as(C.c_void_p), n)
 assert rc == 0, rc
@@ -48,6 +48,14 @@ for name, col, rc in (("pairs", 12, 14), ("quads", 13, 15)):
     sel = buf[:, col] > 0
     if sel.any():
         print("to %s     " % name, q(us(buf[sel, col])), " (%d waves; rounds in that mode, median %d)" % (int(sel.sum()), int(np.median(buf[sel, rc]))))
+f = lambda k, m=slice(None): buf[m, k].astype(np.float64).sum()
+if f(15) > 0:
+    for name, m in (("all waves", slice(None)), ("the last 5 % to end", end >= np.percentile(end, 95))):
+        r4 = f(15, m)
+        print("quad rounds of %s (shader-clock cycles, three clock reads of ~100 each per round included): %d rounds of %.0f cycles with %.1f rays; "
+              "box steps in %.0f %% of them, %.0f cycles each; leaf steps in %.0f %%, %.0f cycles each; the rest of a round (ballots, exit tests) %.0f"
+              % (name, r4, f(20, m) / r4, f(21, m) / r4, 100 * f(17, m) / r4, f(16, m) / max(1, f(17, m)), 100 * f(19, m) / r4, f(18, m) / max(1, f(19, m)),
+                 (f(20, m) - f(16, m) - f(18, m)) / r4))
 sel = (buf[:, 13] > 0) & (end >= np.percentile(end, 95))
 if sel.any():
     dq = (end[sel] - us(buf[sel, 13])); rq = buf[sel, 15].astype(np.float64)
