@@ -375,6 +375,12 @@ struct StackEntry {
 #define GD_RING_SLOT(i) ((i) % GD_RING)  // i < 1024 + GD_RING: a multiply-shift
 #endif
 
+#ifdef GD_RUN_TIMELINE
+__device__ unsigned long long g_stack_events[4];  // diagnostic build: pushes, pushes that spill an entry to global memory, pops, pops that reload one
+#define GD_STACK_EVENT(k) atomicAdd(&g_stack_events[k], 1ull)
+#else
+#define GD_STACK_EVENT(k)
+#endif
 struct TravStack {
     uint2 *ring_a;           ///< LDS, [GD_RING][BLOCK]: (ref, pe)
     float *ring_b;           ///< LDS, [GD_RING][BLOCK]: he
@@ -386,7 +392,9 @@ struct TravStack {
     /// `writer`: this lane performs the stores. A ray that several lanes carry as identical replicas (the thin-wave modes
     /// below) has ONE column; every replica keeps sp / base and reads the column, only the first one writes it.
     GD_FN void push(StackEntry e, bool writer = true) {
+        if (writer) GD_STACK_EVENT(0);
         if (sp - base == GD_RING) {
+            if (writer) GD_STACK_EVENT(1);
             uint32_t o = GD_RING_SLOT(base) * ring_stride;
             uint2 a = ring_a[o];
             if (writer) spill[(size_t)base * spill_stride] = make_uint4(a.x, a.y, __float_as_uint(ring_b[o]), 0);
@@ -400,7 +408,9 @@ struct TravStack {
         sp++;
     }
     GD_FN StackEntry pop(bool writer = true) {  // precondition: sp > 0
+        if (writer) GD_STACK_EVENT(2);
         if (sp == base) {
+            if (writer) GD_STACK_EVENT(3);
             base--;
             uint4 v = spill[(size_t)base * spill_stride];
             uint32_t o = GD_RING_SLOT(base) * ring_stride;
@@ -601,17 +611,42 @@ GD_FN uint32_t quad_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((i
 template <int CTRL>
 GD_FN float quad_f(float v) { return __uint_as_float(quad_u<CTRL>(__float_as_uint(v))); }
 
-/// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them). Precondition: DESCEND.
+/// What a lane fetches for its ray's next step: its part of the node record — quad `sub` of it (four lanes per ray), or the box of
+/// child `sub` as a = {min, lo ref}, b = {max, hi ref} (two lanes) —, or its triangle of a leaf of one or two triangles (a, b, c).
+struct ThinFetch {
+    float4 a, b, c;
+};
+
+/// Issues the loads for the step `t.state` announces. The pipelined loops call it as soon as a step has decided the next one, so that
+/// the round trip to memory runs beside the other rays' steps; leaves other than triangle pairs fetch inside their step.
 template <int M>
-GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub) {
+GD_FN void thin_fetch(const Scene &sc, const Trav &t, uint32_t sub, ThinFetch &pf) {
     static_assert(M == 2 || M == 4, "two or four lanes per ray");
-    const float4 *rec = sc.recs + 4 * (size_t)t.node;
+    if (t.state == TRAV_DESCEND) {
+        const float4 *rec = sc.recs + 4 * (size_t)t.node;
+        if (M == 4) {
+            pf.a = rec[sub];  // 0: lo.min | lo ref, 1: lo.max | hi ref, 2: hi.min, 3: hi.max
+            asm volatile("" : "+v"(pf.a.w));  // keep the ref in the 16-byte load (see trav_step_box)
+        } else {
+            pf.a = rec[2 * sub]; pf.b = rec[2 * sub + 1];  // sub 0: the lower child's box (and both refs), 1: the upper child's
+            asm volatile("" : "+v"(pf.a.w), "+v"(pf.b.w));
+        }
+    } else if (t.state & 8) {
+        const bool second = (M == 4 ? (sub >> 1) : sub) != 0;
+        const float4 *pa = sc.prims + 3 * (size_t)t.node + ((second && t.state == TRAV_LEAF_TRIS) ? 3 : 0);
+        pf.a = pa[0]; pf.b = pa[1]; pf.c = pa[2];
+    }
+}
+
+/// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them), on the parts of the record the
+/// replicas hold in `pf` (thin_fetch). Precondition: DESCEND.
+template <int M>
+GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf) {
     const float INF = __builtin_inff();
     float e;  // this lane's box: entry parameter, GD_ENTRY_MISS when not hit
     uint32_t ref_lo, ref_hi;
     if (M == 4) {
-        float4 mine = rec[sub];  // 0: lo.min | lo ref, 1: lo.max | hi ref, 2: hi.min, 3: hi.max
-        asm volatile("" : "+v"(mine.w));  // keep the ref in the 16-byte load (see trav_step_box)
+        const float4 mine = pf.a;
         const F3 other = f3(quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.x), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.y), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.z));
         const bool inside = within(ro.x, mine.x, other.x) & within(ro.y, mine.y, other.y) & within(ro.z, mine.z, other.z);
         const float cx = face_candidate((mine.x - ro.x) * rdiv.x, ro.y, rd.y, mine.y, other.y, ro.z, rd.z, mine.z, other.z);
@@ -624,8 +659,7 @@ GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, T
         ref_lo = quad_u<GD_QUAD_PERM(0, 0, 0, 0)>(__float_as_uint(mine.w));
         ref_hi = quad_u<GD_QUAD_PERM(1, 1, 1, 1)>(__float_as_uint(mine.w));
     } else {
-        float4 bmin = rec[2 * sub], bmax = rec[2 * sub + 1];  // sub 0: the lower child's box (and both refs), 1: the upper child's
-        asm volatile("" : "+v"(bmin.w), "+v"(bmax.w));
+        const float4 bmin = pf.a, bmax = pf.b;
         float pos;
         const bool hit = aabb_entry(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos);
         e = hit ? pos : GD_ENTRY_MISS;
@@ -647,19 +681,24 @@ GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, T
     trav_pop<false>(t, st, nullptr, writer);
 }
 
+/// The same, fetching the record itself (the loops that do not fetch ahead).
+template <int M>
+GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub) {
+    ThinFetch pf;
+    thin_fetch<M>(sc, t, sub, pf);
+    trav_step_box_thin_on<M>(ro, rd, rdiv, t, st, sub, pf);
+}
+
 /// The pending leaf of a ray carried by M replicas, then the pop. A leaf of one or two triangles is split between the halves
-/// of the group; every other leaf runs replicated through the code of `trav_step_leaf`.
+/// of the group (its triangle in `pf`, thin_fetch); every other leaf runs replicated through the code of `trav_step_leaf`.
 template <int M, int TYPES>
-GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub) {
+GD_FN void trav_step_leaf_thin_on(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf) {
     const bool writer = sub == 0;
     constexpr bool SMALL_PATH = (TYPES & 0xF) != ((1 << P_DISC) | (1 << P_TRIANGLE));
     const Ray r{ro, rd};
     if (t.state & 8) {
         const bool two = t.state == TRAV_LEAF_TRIS;
-        const bool second = (M == 4 ? (sub >> 1) : sub) != 0;
-        const float4 *pa = sc.prims + 3 * (size_t)t.node + ((second && two) ? 3 : 0);
-        const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
-        const float tt = triangle_t(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, a0, a1, a2);
+        const float tt = triangle_t(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, pf.a, pf.b, pf.c);
         const float ta = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(tt) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(tt);
         float tb = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(tt) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(tt);
         tb = two ? tb : -1.0f;
@@ -671,6 +710,13 @@ GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack
         leaf_test<false, false, TYPES>(sc, r, t.node, t.closest, t.hit_prim, nullptr);
     }
     trav_pop<false>(t, st, nullptr, writer);
+}
+
+template <int M, int TYPES>
+GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub) {
+    ThinFetch pf;
+    thin_fetch<M>(sc, t, sub, pf);  // (a state that is not a triangle leaf fetches nothing here)
+    trav_step_leaf_thin_on<M, TYPES>(sc, ro, rd, t, st, sub, pf);
 }
 
 /// Runs one query to completion (megakernels and test hooks).

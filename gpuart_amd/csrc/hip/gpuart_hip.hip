@@ -1302,6 +1302,15 @@ int gpuart_hip_debug_run_timeline(gpuart_hip_ctx *c, unsigned long long *out, si
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_timeline), waves * 24 * sizeof(unsigned long long)));
     return 0;
 }
+/// diagnostic builds only: reads (and clears) the traversal-stack event counters (pushes, spilling pushes, pops, reloading pops)
+int gpuart_hip_debug_stack_events(gpuart_hip_ctx *c, unsigned long long *out) {
+    if (!c || !out) return GPUART_HIP_ERR_ARG;
+    static unsigned long long zero[4];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gd::g_stack_events), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gd::g_stack_events), zero, sizeof(zero)));
+    return 0;
+}
 /// diagnostic builds only: reads (and clears) the busy-lane histogram of the k_run launches since the last call, 256 words
 int gpuart_hip_debug_run_hist(gpuart_hip_ctx *c, unsigned long long *out) {
     if (!c || !out) return GPUART_HIP_ERR_ARG;

@@ -51,6 +51,10 @@
 #ifndef RUN_TAIL_DIV
 #define RUN_TAIL_DIV 2                ///< tail: retire / shade once the finished lanes are 1/RUN_TAIL_DIV of the traversing ones
 #endif
+#ifndef RUN_PIPE
+#define RUN_PIPE 1                    ///< thin modes fetch ahead: what a ray's next step needs is requested as soon as the step before has decided
+                                      ///< it, and a leaf entered in this round is tested in the next one, after its triangles have arrived
+#endif
 #ifndef RUN_THIN
 #define RUN_THIN 4                    ///< most lanes per ray in the tail (1: never leave wide mode; 2; 4). Once the cursor is dry and a wave is
                                       ///< down to 32 (16) live paths and queries in flight, its rays are carried by pairs (quads) of lanes
@@ -333,32 +337,59 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             auto thin_rounds = [&](auto width) {
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
+#if RUN_PIPE
+                // Software-pipelined: a ray's record / triangles are requested the moment the step before has decided what comes next
+                // (thin_fetch), and a triangle leaf entered in this round's box phase is tested in the NEXT round's leaf phase — its
+                // data then arrives beside the other rays' steps instead of stalling the whole wave at the head of the leaf phase.
+                ThinFetch pf;
+                pf.a = pf.b = pf.c = make_float4(0, 0, 0, 0);
+                thin_fetch<W>(sc, t, sub, pf);
+                bool fresh = false;  // this lane's leaf was entered in this round: its triangles are on their way
+#endif
                 for (;;) {
 #ifdef GD_RUN_TIMELINE
                     const unsigned long long pc0 = __builtin_amdgcn_s_memtime();
-                    if (__ballot(t.state == TRAV_DESCEND)) {
-                        if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
-                        if (W == 4) { tp_box += __builtin_amdgcn_s_memtime() - pc0; tp_nbox++; }
+#endif
+#if RUN_PIPE
+                    if (t.state == TRAV_DESCEND) {
+                        trav_step_box_thin_on<W>(ro, rd, rdiv, t, st, sub, pf);
+                        thin_fetch<W>(sc, t, sub, pf);
+                        fresh = (t.state & 8) != 0;
                     }
+                    const bool leaf_now = (t.state & 1) != 0 && !fresh;
 #else
                     if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    const bool leaf_now = (t.state & 1) != 0;
 #endif
-                    unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
+#ifdef GD_RUN_TIMELINE
+                    if (W == 4) { tp_box += __builtin_amdgcn_s_memtime() - pc0; tp_nbox++; }
+#endif
+                    unsigned long long at_leaf = __ballot(leaf_now) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
                     if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
 #ifdef GD_RUN_TIMELINE
                         const unsigned long long pl0 = __builtin_amdgcn_s_memtime();
 #endif
-                        if (t.state & 1) {
+                        if (leaf_now) {
+#if RUN_PIPE
+                            trav_step_leaf_thin_on<W, TYPES>(sc, ro, rd, t, st, sub, pf);
+#else
                             trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+#endif
                             if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
+#if RUN_PIPE
+                            thin_fetch<W>(sc, t, sub, pf);
+#endif
                         }
                         busy = __ballot(t.state != TRAV_DONE) & LEAD;
 #ifdef GD_RUN_TIMELINE
                         if (W == 4) { tp_leaf += __builtin_amdgcn_s_memtime() - pl0; tp_nleaf++; }
 #endif
                     }
+#if RUN_PIPE
+                    fresh = false;
+#endif
 #ifdef GD_RUN_TIMELINE
                     if (W == 4) { tp_loop += __builtin_amdgcn_s_memtime() - pc0; tp_busy += (uint32_t)__popcll(busy); }
 #endif

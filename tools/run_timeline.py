@@ -29,6 +29,11 @@ for it in range(3):
     for _ in range(K):
         r.path_tracing_pass()
     r.finish()
+ev = np.zeros(4, np.uint64)
+L.gpuart_hip_debug_stack_events.argtypes = [C.c_void_p, C.c_void_p]
+L.gpuart_hip_debug_stack_events(r.backend.ctx, ev.ctypes.data_as(C.c_void_p))
+print("traversal stack, all launches of this process: %d pushes, %d of them spill an entry to global memory (%.1f %%); %d pops, %d reload one (%.1f %%)"
+      % (ev[0], ev[1], 100.0 * ev[1] / max(1, ev[0]), ev[2], ev[3], 100.0 * ev[3] / max(1, ev[2])))
 n = 4096
 buf = np.zeros((n, 24), np.uint64)
 L.gpuart_hip_debug_run_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
