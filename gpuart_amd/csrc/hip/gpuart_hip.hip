@@ -1063,6 +1063,18 @@ int wait_stream(gpuart_hip_ctx *c, uint32_t timeout_ms, const char *what) {
 }  // namespace
 }  // extern "C++"
 
+int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *status, int n, int which, int root) {
+    if (!shares || n < 1 || n > 1024) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    std::vector<GatherHello> all((size_t)n);
+    for (int k = 0; k < n; k++) {
+        memset(&all[(size_t)k], 0, sizeof(GatherHello));
+        all[(size_t)k].g = shares[k];
+        all[(size_t)k].status = status ? status[k] : 0u;
+        all[(size_t)k].which = (uint32_t)which; all[(size_t)k].root = (uint32_t)root;
+    }
+    return check_shares(all, which, root);
+}
+
 int gpuart_hip_comm_info(gpuart_hip_ctx *c, int *nranks, int *rank) {
     if (!c || !c->comm) return fail(GPUART_HIP_ERR_ARG, "no communicator (gpuart_hip_comm_init)");
     int r = need_rccl();

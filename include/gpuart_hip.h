@@ -227,6 +227,11 @@ int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims,
  * Returns the number of runs (which may exceed max_runs: only the first max_runs are stored), or a negative error. */
 int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_ops, uint32_t *runs, int max_runs);
 
+/* The validation every rank of gpuart_hip_gather applies to the exchanged share table (pure host code): `shares[k]` and
+ * `status[k]` (0: ready) as rank k announced them. 0 if the gather would go ahead — full-width rows, every frame row covered
+ * exactly once, every rank ready — else the error code it would return on every rank (gpuart_hip_last_error says why). */
+int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *status, int n, int which, int root);
+
 /* ---- device-function test hooks (parity tests call the device code through these) ----------
  * Arrays are n x 4 float32 in host memory. Each mirrors one reference GLSL function. */
 int gpuart_hip_test_random(gpuart_hip_ctx *ctx, const float *in, int n, float *out);

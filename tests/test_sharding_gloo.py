@@ -41,6 +41,38 @@ def test_c_share_layout_matches_the_numpy_restatement():
         B.share_of_rank(64, 64, 2, 2)
 
 
+def test_share_table_validation_of_the_gather():
+    """What every rank of gpuart_hip_gather checks before any transfer is posted (csrc/hip/gpuart_hip.hip check_shares, through
+    gpuart_hip_test_share_table): the library's own round-robin shares pass for every rank count — also with more ranks than bands —,
+    and a table that leaves rows to nobody, deals a row twice, mixes frame sizes, holds a partial-width share or a rank that
+    reported a failure is refused with the same verdict on every rank."""
+    import ctypes as C
+    from gpuart_amd import binding as B
+    L = B.hip_lib()
+
+    def verdict(shares, status=None):
+        arr = (B.TileGeom * len(shares))(*shares)
+        st = None if status is None else (C.c_uint32 * len(shares))(*status)
+        rc = L.gpuart_hip_test_share_table(arr, st, len(shares), 1, 0)
+        return rc, L.gpuart_hip_last_error().decode()
+
+    for W, H in ((1920, 1080), (37, 61), (64, 8), (5, 3)):
+        for n in (1, 2, 3, 8, 11):
+            for band in (1, 3, 8, 16):
+                shares = [B.share_of_rank(W, H, r, n, band) for r in range(n)]
+                assert verdict(shares)[0] == 0, (W, H, n, band, verdict(shares)[1])
+    W, H = 64, 48
+    good = [B.share_of_rank(W, H, r, 3) for r in range(3)]
+    assert any(g.th == 0 for g in [B.share_of_rank(64, 8, r, 4) for r in range(4)])  # (empty shares were part of the loop above)
+    rc, why = verdict(good[:2] + [good[1]]); assert rc != 0 and "overlap" in why
+    rc, why = verdict(good[:2]); assert rc != 0 and "belongs to no rank" in why
+    rc, why = verdict([good[0], good[1], B.share_of_rank(W, H + 8, 2, 3)]); assert rc != 0 and "inconsistent" in why
+    narrow = B.share_of_rank(W, H, 2, 3); narrow.tw = W - 8
+    rc, why = verdict([good[0], good[1], narrow]); assert rc != 0 and "full-width" in why
+    rc, why = verdict(good, status=[0, 1, 0]); assert rc != 0 and "rank 1 could not prepare" in why
+    assert verdict(good, status=[0, 0, 0])[0] == 0
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
