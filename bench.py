@@ -532,7 +532,10 @@ def main():
     roof.update({"bound": "valu_issue", "achieved": vi.get("achieved"), "peak": vi["peak"], "unit": vi["unit"], "frac": vi.get("frac"),
                  "definition": vi["definition"] + ". Beside it: `l1_accesses` (vector-L1 cache accesses against the highest rate measured on the box) and "
                                "`node_visits` (executed node visits against the micro-benchmarked rate of the same traversal step); `traffic` = HBM "
-                               "bytes per pass from the PMC counters"})
+                               "bytes per pass from the PMC counters. NOTE: `frac` is a share of ISSUE SLOTS, not of useful work — removing "
+                               "wasted instructions lowers it: round 3's thin-wave modes issue 5.7e8 instead of 6.4e8 VALU instructions per "
+                               "pass (same rays, same node visits) in 6 % less time, which moves `frac` from 0.56 to 0.53 while "
+                               "`node_visits.frac` rises from 0.87 to 0.89-0.90"})
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample, rank 0, N=1 only ----
     cpu_baseline = None
