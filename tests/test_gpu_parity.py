@@ -1105,6 +1105,28 @@ def test_headless_cli_gather_path(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+def test_frame_sharded_over_several_gpus_equals_the_single_gpu_frame(tmp_path):
+    """Where the box has more than one GPU (the driver's 8-GPU node; a one-GPU box skips): gpuart_cli --gpus N renders one frame
+    as N interleaved shares on N devices and gathers it through RCCL inside the library (ncclCommInitAll, share + status
+    all-gather, grouped send / recv to the root, row scatter) — the PFM must equal the single-GPU one byte for byte. This is the
+    only place where the N > 1 transfers of gpuart_hip_gather_all run under test."""
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU: the multi-rank RCCL transfers need at least two devices")
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpuart_amd", "bin", "gpuart_cli")
+    base = [exe, "--scene", "box", "--width", "200", "--height", "136", "--mode", "pt", "--spp", "4"]
+    one = str(tmp_path / "one.pfm")
+    out = subprocess.run(base + ["--pfm", one], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    for n in sorted({2, min(n_dev, 4), min(n_dev, 8)}):
+        many = str(tmp_path / ("gpus%d.pfm" % n))
+        out = subprocess.run(base + ["--gpus", str(n), "--pfm", many], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert open(one, "rb").read() == open(many, "rb").read(), "%d GPUs: the gathered frame differs from the single-GPU frame" % n
+
+
 # ---- row N1 of SURVEY 8(f): the product's own loaders and scenes, on the GPU ------------------------------------------
 def _loader_case(name, tmp_path):
     """(renderer.init_*(file written for it), camera selector) for a frames_<name>*.npz fixture."""
