@@ -383,13 +383,14 @@ class Backend:
 
     def test_aabb(self, rs, rd, bmin, bmax): return self._hook("gpuart_hip_test_aabb", [rs, rd, bmin, bmax], 1)[0]
 
-    def test_traverse(self, rs, rd, user_sphere, any_hit=False):
+    def test_traverse(self, rs, rd, user_sphere, any_hit=False, nearest_first=False):
+        """any_hit: only "anything hit?"; nearest_first: the closest-hit query in the order of the fast kernels (nearer child first)."""
         rs = np.ascontiguousarray(rs, np.float32)
         rd = np.ascontiguousarray(rd, np.float32)
         n = rs.shape[0]
         o0, o1 = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
         us = (C.c_float * 4)(*[float(x) for x in user_sphere])
-        self._chk(self.L.gpuart_hip_test_traverse(self.ctx, _p(rs), _p(rd), us, C.c_int(n), C.c_int(1 if any_hit else 0),
+        self._chk(self.L.gpuart_hip_test_traverse(self.ctx, _p(rs), _p(rd), us, C.c_int(n), C.c_int(2 if nearest_first else 1 if any_hit else 0),
                                                   _p(o0), _p(o1)))
         return o0, o1
 

@@ -1289,12 +1289,14 @@ int gpuart_hip_test_aabb(gpuart_hip_ctx *c, const float *rs, const float *rd, co
 int gpuart_hip_test_traverse(gpuart_hip_ctx *c, const float *rs, const float *rd, const float us[4], int n, int any_hit,
                              float *out0, float *out1) {
     if (!c || !c->have_scene || !us) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
+    if (any_hit == 2 && c->exact_boxes) return fail(GPUART_HIP_ERR_ARG, "a tree with irregular boxes is only walked in the reference's order");
     Float4Arg a; memcpy(a.v, us, 16);
     Scene sc = scene_of(c);
     const float *ins[] = {rs, rd}; float *outs[] = {out0, out1};
     return run_hook(c, n, ins, 2, outs, 2, [&](auto &i, auto &o) {
         dim3 grid(std::min<uint32_t>(c->grid_waves, (uint32_t)((n + BLOCK - 1) / BLOCK)));
-        if (any_hit) k_test_traverse<true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1], c->d_spill);
+        if (any_hit == 2) k_test_traverse<false, true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1], c->d_spill);
+        else if (any_hit) k_test_traverse<true><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1], c->d_spill);
         else k_test_traverse<false><<<grid, BLOCK, 0, c->stream>>>(sc, i[0], i[1], a, n, o[0], o[1], c->d_spill);
     });
 }

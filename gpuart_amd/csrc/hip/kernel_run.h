@@ -118,6 +118,8 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     // every group, `sub` = this lane's index in its group. Never entered by the
     // counting variants (their counters are per lane) and by trees with irregular boxes (comparison-form box tests).
     constexpr bool THIN_OK = RUN_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    // closest-hit queries enter the nearer child first (device_scene.h, GD_NEAREST); the counters of mode 4 count that walk
+    constexpr bool NEAR = GD_NEAREST && !REFWORK && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
     uint32_t M = 1, sub = 0;                                   // M wave-uniform
     unsigned long long lead = ~0ull;                           // wave-uniform
     __shared__ uint32_t xfer[BLOCK];
@@ -352,13 +354,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
 #if RUN_PIPE
                     if (t.state == TRAV_DESCEND) {
-                        trav_step_box_thin_on<W>(ro, rd, rdiv, t, st, sub, pf);
+                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, GD_NEAREST_SHADOW || !(ent & RUN_F_SHADOW));
                         thin_fetch<W>(sc, t, sub, pf);
                         fresh = (t.state & 8) != 0;
                     }
                     const bool leaf_now = (t.state & 1) != 0 && !fresh;
 #else
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, GD_NEAREST_SHADOW || !(ent & RUN_F_SHADOW));
                     const bool leaf_now = (t.state & 1) != 0;
 #endif
 #ifdef GD_RUN_TIMELINE
@@ -373,9 +375,9 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
                         if (leaf_now) {
 #if RUN_PIPE
-                            trav_step_leaf_thin_on<W, TYPES>(sc, ro, rd, t, st, sub, pf);
+                            trav_step_leaf_thin_on<W, TYPES, NEAR>(sc, ro, rd, t, st, sub, pf);
 #else
-                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub);
 #endif
                             if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
 #if RUN_PIPE
@@ -405,13 +407,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             else thin_rounds(std::integral_constant<int, 4>());
         } else
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, GD_NEAREST_SHADOW || !(ent & RUN_F_SHADOW));
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
-                    trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                    trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
                     if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                 }

@@ -243,6 +243,8 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     // Thin-wave modes (device_scene.h): once the queue is empty and the wave is down to 32 (16) rays, pairs (quads) of lanes carry
     // them. Not in the counting variant (its counters are per lane) nor for trees with irregular boxes.
     constexpr bool THIN_OK = GD_TRACE_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    // closest-hit queries enter the nearer child first (device_scene.h, GD_NEAREST): same answer, fewer node visits
+    constexpr bool NEAR = GD_NEAREST && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
     uint32_t M = 1, sub = 0;  // M wave-uniform
     const uint32_t *queue_c = b.queue[seg_c & 1];
     const uint32_t n_c = seg_c >= 0 ? b.counters[4 * seg_c] : 0u;
@@ -319,13 +321,13 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, GD_NEAREST_SHADOW || !shadow);
                     const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
                     if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
                         if (t.state & 1) {
-                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub);
                             if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                         }
                         busy = __ballot(t.state != TRAV_DONE) & LEAD;
@@ -340,7 +342,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         } else
         // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr);
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, GD_NEAREST_SHADOW || !shadow);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             // leaves are tested once 1/leaf_share of the lanes that still have a ray wait at one (at most leaf_lanes):
@@ -348,7 +350,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
-                    trav_step_leaf<false, COUNT, TYPES>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                    trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
                     if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                 }
@@ -497,6 +499,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
     // thin-wave modes (device_scene.h) for the end of the frame: once the pixel cursor is dry and the wave is down to 32 (16)
     // pixels, pairs (quads) of lanes carry them
     constexpr bool THIN_OK = GD_TRACE_THIN > 1 && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    constexpr bool NEAR = GD_NEAREST && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;  // nearer child first (device_scene.h, GD_NEAREST)
     uint32_t M = 1, sub = 0;  // M wave-uniform
     const float AMBIENT = 0.15f;
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
@@ -578,13 +581,13 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W>(sc, ro, rd, rdiv, t, st, sub);
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, GD_NEAREST_SHADOW || stage != DL_SUN);
                     const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
                     if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
                         if (t.state & 1) {
-                            trav_step_leaf_thin<W, TYPES>(sc, ro, rd, t, st, sub);
+                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub);
                             if (stage == DL_SUN && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;  // only "anything hit?" is asked
                         }
                         busy = __ballot(t.state != TRAV_DONE) & LEAD;
@@ -600,13 +603,13 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
         } else
         // ---- traverse until enough lanes have an answer (a lane without a pixel is in state DONE)
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<false, GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, nullptr);
+            if (t.state == TRAV_DESCEND) trav_step_box<false, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, nullptr, GD_NEAREST_SHADOW || stage != DL_SUN);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
-                    trav_step_leaf<false, false, TYPES>(sc, Ray{ro, rd}, t, st, nullptr);
+                    trav_step_leaf<false, false, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, nullptr);
                     if (stage == DL_SUN && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;  // only "anything hit?" is asked
                 }
                 descending = __ballot(t.state == TRAV_DESCEND);

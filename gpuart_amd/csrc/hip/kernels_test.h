@@ -61,7 +61,7 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
     bool h = regular ? aabb_entry(r, rdiv, lo, hi, pos) : aabb_entry<true>(r, rdiv, lo, hi, pos);
     out[i] = make_float4(h ? 1.0f : 0.0f, h ? pos : 0.0f, 0, 0);
 }
-template <bool ANY>
+template <bool ANY, bool NEAREST = false>
 __global__ void __launch_bounds__(BLOCK) k_test_traverse(Scene sc, const float4 *rs, const float4 *rd, Float4Arg us, int n,
                                                          float4 *o0, float4 *o1, uint4 *spill) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(BLOCK) k_test_traverse(Scene sc, const float4 
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
         float closest; uint32_t prim;
-        traverse<ANY, false>(sc, r, st, closest, prim, nullptr);
+        traverse<ANY, false, NEAREST>(sc, r, st, closest, prim, nullptr);
         if (ANY) {
             o0[i] = make_float4(prim != GD_NO_PRIM ? 1.0f : 0.0f, 0, 0, 0);
             o1[i] = make_float4(0, 0, 0, 0);

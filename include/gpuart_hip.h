@@ -247,7 +247,9 @@ int gpuart_hip_test_intersect(gpuart_hip_ctx *ctx, int ptype, const float *rs, c
 int gpuart_hip_test_aabb(gpuart_hip_ctx *ctx, const float *rs, const float *rd, const float *bmin, const float *bmax,
                          int n, float *out);
 /* Closest-hit query over the uploaded tree incl. the user sphere; out0 = (pos, P), out1 = (N, type
- * (+0.5 if the user sphere was hit), or -1 on a miss). any_hit != 0: out0[0] = 1/0 only. */
+ * (+0.5 if the user sphere was hit), or -1 on a miss). any_hit == 1: out0[0] = 1/0 only. any_hit == 2: the closest-hit
+ * query in the order of the fast kernels (nearer child first, lower primitive index wins equal parameters; trees of regular
+ * boxes only) — it must return what the reference's order returns. */
 int gpuart_hip_test_traverse(gpuart_hip_ctx *ctx, const float *rs, const float *rd, const float userSphere[4], int n,
                              int any_hit, float *out0, float *out1);
 /* Camera rays of the context's tile: rstart / rdir, tw*th*4 floats each. */
