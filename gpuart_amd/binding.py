@@ -29,7 +29,7 @@ class Params(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("prim_tests", C.c_uint64 * 4), ("segments", C.c_uint64),
-                ("box_steps", C.c_uint64), ("box_steps_top", C.c_uint64)]
+                ("box_steps", C.c_uint64), ("box_steps_top", C.c_uint64), ("rewalks", C.c_uint64)]
 
     def algorithmic_bytes(self):
         """48 B per distinct node + (16 + 16*len) B per tested primitive."""

@@ -84,6 +84,50 @@ struct Converter {
             irregular = irregular || !(c.bmin[k] <= c.bmax[k]) || std::isinf(c.bmin[k]) || std::isinf(c.bmax[k]);  // NaN fails <=
     }
 
+    /// May the fast kernels visit this tree's nodes in their own order (nearer child first, device_scene.h GD_NEAREST)? Their
+    /// certificate rests on boxes that bound what they hold: every child box inside its parent's, every primitive inside its
+    /// leaf's box by the very formulas the reference's constructors use (reference src/core.cpp:36-65,80-90,136-150,217-225) —
+    /// which only bound a primitive with radii >= 0 and, for a cone, with derived constants (axis, length, width coefficient)
+    /// that agree with its two centres and radii. Hostile input (negative radii, NaN, a hand-made tree) fails this and keeps
+    /// the reference's order throughout, like a tree with irregular boxes.
+    bool disorderly = false;
+    static bool box_in_box(const float *cmin, const float *cmax, const float *bmin, const float *bmax) {
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok = ok && cmin[k] >= bmin[k] && cmax[k] <= bmax[k] && cmin[k] <= cmax[k];  // NaN fails
+        return ok;
+    }
+    static bool prim_in_box(uint32_t type, const float *d, const float *bmin, const float *bmax) {
+        float lo[3], hi[3];
+        // Coordinates beyond 2^20 (the hostile classes use 1e10 ... 1e30): the intersectors' own arithmetic cancels there — a
+        // vertex at -1e30 swallows the ray origin in `origin - v0` — and a hit parameter that is off by more than the band says
+        // nothing about the box it came from. (ulp(2^20) = 0.06: no scene a float path tracer renders sensibly is excluded.)
+        static const int LEN[4] = {4, 8, 12, 12};
+        for (int k = 0; k < LEN[type & 3]; k++)
+            if (!(std::fabs(d[k]) <= 1048576.0f) && !(type == P_TRIANGLE && (k & 3) == 3)) return false;
+        switch (type) {
+        case P_SPHERE:
+        case P_DISC:  // (the reference bounds a disc by the sphere of its radius)
+            if (!(d[3] >= 0)) return false;
+            for (int k = 0; k < 3; k++) { lo[k] = d[k] - d[3]; hi[k] = d[k] + d[3]; }
+            break;
+        case P_TRIANGLE:
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(d[k], std::min(d[4 + k], d[8 + k])); hi[k] = std::max(d[k], std::max(d[4 + k], d[8 + k])); }
+            break;
+        case P_CONE: {
+            const float r1 = d[3], r2 = d[7], len = d[11], wc = d[12];
+            if (!(r1 >= 0) || !(r2 >= 0) || !(len >= 0)) return false;
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(d[k] - r1, d[4 + k] - r2); hi[k] = std::max(d[k] + r1, d[4 + k] + r2); }
+            // the intersector works from (centre 1, radius 1, axis, length, width coefficient): they must describe the same frustum
+            const float tol = 1.0e-4f * (len + r1 + r2) + 1.0e-30f;
+            for (int k = 0; k < 3; k++) if (!(std::fabs(d[k] + len * d[8 + k] - d[4 + k]) <= tol)) return false;
+            if (!(std::fabs(r1 + wc * len - r2) <= tol)) return false;
+            break;
+        }
+        default: return false;
+        }
+        return box_in_box(lo, hi, bmin, bmax);
+    }
+
     /// What the scan keeps of a canonical node: where it lies, the ref its parent stores for it, and (interior nodes) which
     /// entry of the table its upper child is — its lower child is the next entry (pre-order).
     struct NodeInfo {
@@ -152,7 +196,7 @@ struct Converter {
 
     /// Pass 2 — the entries [from, to) of the table into the device arrays (disjoint writes: any number of threads).
     /// Returns whether one of the boxes written is irregular.
-    bool fill(size_t from, size_t to) {
+    bool fill(size_t from, size_t to, bool &loose) {
         bool irr = false;
         auto bad = [](const Child &c) {
             bool r = false;
@@ -170,6 +214,7 @@ struct Converter {
                 for (uint32_t k = 0; k < cnt; k++) {
                     const uint32_t type = bits(q[4 * a]);
                     pack_prim(type, q + 4 * (a + 1), dst + 3 * k);
+                    loose = loose || !prim_in_box(type, q + 4 * (a + 1), b, b + 4);
                     if (k == 0) dst[0].w = fbits(type | (cnt << 2));  // the first primitive carries the leaf's count
                     a += 1 + LEN[type];
                 }
@@ -177,6 +222,7 @@ struct Converter {
             } else {
                 const Child L = child_of(table[i + 1]), H = child_of(table[n.hi_index]);
                 irr = irr || bad(L) || bad(H);
+                loose = loose || !box_in_box(L.bmin, L.bmax, b, b + 4) || !box_in_box(H.bmin, H.bmax, b, b + 4);
                 float4 *r = recs.data() + 4 * (size_t)n.ref;
                 r[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
                 r[1] = make_float4(L.bmax[0], L.bmax[1], L.bmax[2], fbits(H.ref));
@@ -199,15 +245,16 @@ struct Converter {
         note(root);
         const size_t n = table.size();
         const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 16384));
-        std::vector<char> irr(parts, 0);
+        std::vector<char> irr(parts, 0), loose(parts, 0);
         std::vector<std::thread> pool;
-        auto work = [&](unsigned k) { irr[k] = fill(n * k / parts, n * (size_t)(k + 1) / parts) ? 1 : 0; };
+        auto work = [&](unsigned k) { bool l = false; irr[k] = fill(n * k / parts, n * (size_t)(k + 1) / parts, l) ? 1 : 0; loose[k] = l ? 1 : 0; };
         for (unsigned k = 1; k < parts; k++) {
             try { pool.emplace_back(work, k); } catch (const std::system_error &) { work(k); }
         }
         work(0);
         for (auto &t : pool) t.join();
         for (char v : irr) irregular = irregular || v;
+        for (char v : loose) disorderly = disorderly || v;
         std::vector<NodeInfo>().swap(table);
         return true;
     }

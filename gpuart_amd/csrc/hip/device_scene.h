@@ -32,18 +32,38 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #define GD_REF_INDEX 0x0fffffffu
 
 // Nearest-child-first closest-hit queries (round 4). The reference always descends lower-then-upper
-// (shaders/bvh_intersection.glsl:432-441) and keeps the strictly closer hit (:416), i.e. among the hits with the smallest
-// parameter the FIRST primitive in its depth-first order = the one with the lowest address. A walk that enters the child
-// whose box is entered first and stacks the other one, prunes with the same `entry > closest` and breaks ties of equal
-// parameters by the lower primitive index returns the same (closest, primitive) while it visits ~18 % fewer records.
-// The fast kernels walk that way (NEAREST template arguments below); the counting "reference work" variants, trees with
-// irregular boxes and the one-thread-per-pixel kernels keep the reference's order.
+// (shaders/bvh_intersection.glsl:432-441), prunes a node whose box is entered beyond the closest hit so far (:398) and keeps the
+// strictly closer hit (:416): among the hits with the smallest parameter the FIRST primitive in its depth-first order = the one
+// with the lowest address wins. If every box were conservative for what it holds — entered no later than any hit inside it — that
+// winner would not depend on the visiting order, and a walk that enters the nearer child first, stacks the other one and lets the
+// lower primitive index win equal parameters would return it after ~18 % fewer node visits. In fp32 boxes are NOT always
+// conservative: a box entry parameter and a primitive's own hit parameter are computed two ways, and where the hit lies on the
+// box's face (flat axis-aligned triangles, a sphere's axis-extreme points, a triangle's extreme vertex) either may come out a few
+// ulps larger. Then the reference's pruning — and so its winner among surfaces that (nearly) coincide — hinges on its order:
+// measured, 3 of 1e9 rays of cfg3 and every tenth scene of coplanar lattice geometry (profiles/r04/nearest_child_first.txt).
+// The fast kernels therefore walk nearest-first WITH a certificate (NEAREST template arguments below):
+//   * pruning is widened by GD_NEAREST_BAND: a node is skipped only if the largest entry parameter on its path exceeds
+//     closest x BAND, so every primitive within the band of the final hit is tested whatever the order;
+//   * the query tracks the runner-up (second smallest accepted parameter) and whether the winner is "loose": some box on its
+//     path is entered beyond the winner's own parameter (only then can the reference have pruned it);
+//   * a finished query whose winner is loose AND has a runner-up within the band is walked again in the reference's order
+//     (one ray in ~1e4 on meshes) — trav_settle.
+// Why this suffices: let (t*, p*) be the nearest-first result, R the reference's. If every hit primitive's boxes are entered no
+// later than its parameter x (1 + eps), with BAND >= (1 + eps)^2: R was tested by the nearest-first walk, so t_R >= t*; the
+// reference can only have missed p* through a box on p*'s path entered beyond t* (p* loose) while it held another hit with
+// t* <= t < that entry (a runner-up within the band) — and when it did test p*, the winner by (parameter, index) is the same in
+// both walks. eps is 6e-5 = 1000 ulps here; a primitive whose computed parameter is off by more (a triangle hit at a grazing
+// angle below 1e-3 rad AND in such a constellation) is outside the certificate. The counting "reference work" variants, trees
+// with irregular boxes and the one-thread-per-pixel kernels keep the reference's order throughout.
 #ifndef GD_NEAREST
 #define GD_NEAREST 1
 #endif
-#ifndef GD_NEAREST_SHADOW
-#define GD_NEAREST_SHADOW 0  ///< 1: the fast mode's Sun-shadow queries (first accepted hit settles them) order their children too
+#ifndef GD_NEAREST_BAND
+#define GD_NEAREST_BAND 1.00390625f  ///< 1 + 2^-8 (free up to 2^-8, +2.5 % time at 2^-6: profiles/r04/nearest_child_first.txt)
 #endif
+#define GD_PRIM_LOOSE 0x40000000u  ///< in Trav::hit_prim during a NEAREST walk: a box on the winner's path is entered beyond the winner's parameter
+#define GD_PRIM_ADRIFT 0x20000000u ///< ... beyond the winner's parameter x BAND: the parameter and its boxes disagree by more than rounding
+#define GD_PRIM_FLAGS (GD_PRIM_LOOSE | GD_PRIM_ADRIFT)
 
 struct Scene {
     const float4 *__restrict__ recs;
@@ -67,6 +87,7 @@ struct Surface {
 struct WorkCounters {
     uint32_t rays, nodes, prims[4];
     uint32_t steps, steps_top;  ///< interior-node visits (record fetches); those of records the uploader marked "top of the tree"
+    uint32_t rewalks;           ///< queries a nearest-first walk could not certify and walked again in the reference's order (trav_settle)
 };
 
 // ---- reference shaders/sphere.glsl:31-70 -----------------------------------------------------
@@ -259,39 +280,74 @@ GD_FN bool aabb_entry_exact(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos)
     return inside | hit;
 }
 
-template <bool EXACT = false>
-GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos) {
+/// `odd` (fast form, when asked for): the box is hit from outside, but the entry parameter the reference's running minimum
+/// arrives at is NOT the slab entry — the largest of the three axes' nearer plane parameters, which is what it equals, bit
+/// for bit, whenever the face the ray enters through passes its own test. Where rounding fails that face (a ray through an
+/// edge or a corner) the minimum falls on the face the ray LEAVES through: the box then reports an entry parameter larger than
+/// hits inside it by up to its whole depth, and what the reference finds in it depends on when its walk gets there
+/// (1 ray in ~1e8; device_scene.h top, trav_settle).
+template <bool EXACT = false, bool WITH_ODD = false>
+GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos, bool *odd = nullptr) {
     if (EXACT) return aabb_entry_exact(r, rdiv, bmin, bmax, pos);
     const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
-    const float c0 = face_candidate((bmin.x - r.o.x) * rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
-    const float c1 = face_candidate((bmax.x - r.o.x) * rdiv.x, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
-    const float c2 = face_candidate((bmin.y - r.o.y) * rdiv.y, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z);
-    const float c3 = face_candidate((bmax.y - r.o.y) * rdiv.y, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z);
-    const float c4 = face_candidate((bmin.z - r.o.z) * rdiv.z, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y);
-    const float c5 = face_candidate((bmax.z - r.o.z) * rdiv.z, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y);
+    const float k0 = (bmin.x - r.o.x) * rdiv.x, k1 = (bmax.x - r.o.x) * rdiv.x;
+    const float k2 = (bmin.y - r.o.y) * rdiv.y, k3 = (bmax.y - r.o.y) * rdiv.y;
+    const float k4 = (bmin.z - r.o.z) * rdiv.z, k5 = (bmax.z - r.o.z) * rdiv.z;
+    const float c0 = face_candidate(k0, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c1 = face_candidate(k1, r.o.y, r.d.y, bmin.y, bmax.y, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c2 = face_candidate(k2, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c3 = face_candidate(k3, r.o.x, r.d.x, bmin.x, bmax.x, r.o.z, r.d.z, bmin.z, bmax.z);
+    const float c4 = face_candidate(k4, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y);
+    const float c5 = face_candidate(k5, r.o.x, r.d.x, bmin.x, bmax.x, r.o.y, r.d.y, bmin.y, bmax.y);
     const float best = fminf(fminf(fminf(c0, c1), fminf(c2, c3)), fminf(c4, c5));
     // the reference starts its running minimum at 1e19 and only lowers it with `k < pos`: a face whose k is
     // >= 1e19 still counts as an intersection but leaves pos at 1e19
     const bool hit = best < __builtin_inff();
     pos = inside ? -1.0f : fminf(best, 1.0e+19f);
+    if (WITH_ODD) {
+        const float slab = fmaxf(fmaxf(fminf(k0, k1), fminf(k2, k3)), fminf(k4, k5));
+        *odd = !inside & hit & (best > slab);
+    }
     return inside | hit;
 }
 
-/// Does the hit (pos, primitive pi) replace the closest one so far? The reference's walk meets the primitives in address
-/// order and keeps the strictly closer one; a walk in another order (NEAREST) gets the same winner by letting the lower
-/// index win equal parameters (signed compare: GD_NO_PRIM = -1 never loses a tie it cannot have — closest starts at 1e19
-/// and a hit AT 1e19 is not accepted by the reference's `<` either).
+/// Running result of one query (the traversal state proper follows below).
+struct Trav {
+    float closest;
+    uint32_t hit_prim;   ///< (| GD_PRIM_LOOSE during a NEAREST walk; trav_settle removes it)
+    uint32_t node;       ///< DESCEND: record to fetch; LEAF: first primitive index
+    float entry;         ///< box-entry parameter of the node entered last; in an ordered NEAREST walk the largest one on the path to it
+    int state;
+    float second;        ///< NEAREST walks: parameter of the runner-up (1e19: none)
+};
+
+/// A tested primitive's parameter into the running result; true if it is the closest hit now. The reference's walk meets the
+/// primitives in address order and keeps the strictly closer one (shaders/bvh_intersection.glsl:416). A NEAREST walk gets the same
+/// winner in any order by letting the lower index win equal parameters (signed compare: GD_NO_PRIM = -1 never loses a tie it
+/// cannot have — closest starts at 1e19 and a hit AT 1e19 is not accepted by the reference's `<` either), and keeps what
+/// trav_settle needs: the runner-up's parameter and whether the winner is loose (t.entry, the largest entry parameter on the path
+/// to this leaf, exceeds its parameter).
 template <bool NEAREST>
-GD_FN bool closer(float pos, uint32_t pi, float closest, uint32_t hit_prim) {
-    if (NEAREST) return (pos < closest) | ((pos == closest) & ((int)pi < (int)hit_prim));
-    return pos < closest;
+GD_FN bool take_hit(Trav &t, float pos, uint32_t pi) {
+    if (!(pos > 0)) return false;
+    if (!NEAREST) {
+        if (!(pos < t.closest)) return false;
+        t.closest = pos;
+        t.hit_prim = pi;
+        return true;
+    }
+    const bool win = (pos < t.closest) | ((pos == t.closest) & ((int)pi < (int)(t.hit_prim & ~GD_PRIM_FLAGS)));
+    t.second = fminf(t.second, win ? t.closest : pos);  // (second >= closest unless it is the -inf of an odd box, which sticks)
+    t.hit_prim = win ? (pi | (t.entry > pos ? GD_PRIM_LOOSE : 0u) | (t.entry > pos * GD_NEAREST_BAND ? GD_PRIM_ADRIFT : 0u)) : t.hit_prim;
+    t.closest = win ? pos : t.closest;
+    return win;
 }
 
 /// Tests the primitives of the leaf starting at primitive `first` (its count sits in the first record's
 /// type word); keeps the strictly closer hit (the first one wins ties, reference
 /// shaders/bvh_intersection.glsl:405-423). Returns true if ANY_HIT and something was hit.
 template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES, bool NEAREST = false>
-GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, Trav &t, WorkCounters *wc) {
     uint32_t count = 1;
     for (uint32_t i = 0; i < count; i++) {
         uint32_t pi = first + i;
@@ -303,11 +359,7 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &close
         float pos; F3 p, n; int ptype;
         prim_hit<TYPES>(r, q0, q1, q2, pos, p, n, ptype);
         if (COUNT) wc->prims[ptype & 3]++;
-        if (pos > 0 && closer<NEAREST>(pos, pi, closest, hit_prim)) {
-            closest = pos;
-            hit_prim = pi;
-            if (ANY_HIT) return true;
-        }
+        if (take_hit<NEAREST>(t, pos, pi) && ANY_HIT) return true;
     }
     return false;
 }
@@ -317,7 +369,7 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, float &close
 /// once and a single-triangle leaf requests only its own (every 16-byte request counts: the BVH queries are bound by the
 /// vector-memory request pipeline). The first one wins ties (`pos < closest` is strict), as in the reference's loop.
 template <bool ANY_HIT, bool COUNT, bool NEAREST = false>
-GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool two, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool two, Trav &t, WorkCounters *wc) {
     const float4 *pa = sc.prims + 3 * (size_t)first;
     const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
     if (COUNT) wc->prims[P_TRIANGLE] += two ? 2 : 1;
@@ -335,16 +387,8 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool tw
 #endif
     }
     const float ta = triangle_t(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, a0, a1, a2);
-    if (ta > 0 && closer<NEAREST>(ta, first, closest, hit_prim)) {
-        closest = ta;
-        hit_prim = first;
-        if (ANY_HIT) return true;
-    }
-    if (tb > 0 && closer<NEAREST>(tb, first + 1, closest, hit_prim)) {
-        closest = tb;
-        hit_prim = first + 1;
-        if (ANY_HIT) return true;
-    }
+    if (take_hit<NEAREST>(t, ta, first) && ANY_HIT) return true;
+    if (take_hit<NEAREST>(t, tb, first + 1) && ANY_HIT) return true;
     return false;
 }
 
@@ -352,7 +396,7 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool tw
 /// input): the leaf's ref says which, so a pair's records are requested together instead of one memory round trip per
 /// primitive, and nothing waits for the count in the first record. Same tests in the same order as the loop of `leaf_test`.
 template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES, bool NEAREST = false>
-GD_FN bool leaf_test_small(const Scene &sc, const Ray &r, uint32_t first, bool two, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
+GD_FN bool leaf_test_small(const Scene &sc, const Ray &r, uint32_t first, bool two, Trav &t, WorkCounters *wc) {
     const float4 *pa = sc.prims + 3 * (size_t)first;
     const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
     float tb = -1.0f;
@@ -365,16 +409,8 @@ GD_FN bool leaf_test_small(const Scene &sc, const Ray &r, uint32_t first, bool t
     float ta;
     prim_hit<TYPES>(r, a0, a1, a2, ta, p, n, ptype);
     if (COUNT) wc->prims[ptype & 3]++;
-    if (ta > 0 && closer<NEAREST>(ta, first, closest, hit_prim)) {
-        closest = ta;
-        hit_prim = first;
-        if (ANY_HIT) return true;
-    }
-    if (tb > 0 && closer<NEAREST>(tb, first + 1, closest, hit_prim)) {
-        closest = tb;
-        hit_prim = first + 1;
-        if (ANY_HIT) return true;
-    }
+    if (take_hit<NEAREST>(t, ta, first) && ANY_HIT) return true;
+    if (take_hit<NEAREST>(t, tb, first + 1) && ANY_HIT) return true;
     return false;
 }
 
@@ -463,7 +499,9 @@ struct TravStack {
     }
 };
 
-/// Traversal state of one ray. The walk visits exactly the nodes, in exactly the order, of the
+/// Traversal state of one ray. In the reference's order (every walk that is not an ordered NEAREST one: the counting and
+/// one-thread-per-pixel kernels, trees with irregular boxes, Sun-shadow queries, a query that trav_settle sends round again)
+/// the walk visits exactly the nodes, in exactly the order, of the
 /// reference's stackless parent-pointer walk (shaders/bvh_intersection.glsl:360-457): lower child
 /// first, prune on `entry > closest`. Where the reference re-tests a parent's box when it returns from
 /// the lower child, the parent's entry parameter kept on the stack is compared with the current closest
@@ -476,43 +514,58 @@ static_assert((GD_REF_TRIS >> 27) == 8 && (GD_REF_TWO >> 27) == 4 && (GD_REF_SMA
 
 #define GD_ENTRY_MISS 3.0e+38f  // stack marker: the upper child's box is not hit at all
 
-struct Trav {
-    float closest;
-    uint32_t hit_prim;
-    uint32_t node;       ///< DESCEND: record to fetch; LEAF: first primitive index
-    float entry;         ///< DESCEND: box-entry parameter of the node whose record is `node`
-    int state;
-};
 
 /// Enters a child whose box test passed: a leaf waits for its primitive tests, an interior child for its record.
 GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
+    t.entry = entry;  // (a leaf's: take_hit compares the accepted hit with it)
     if (ref & GD_REF_LEAF) {
         t.node = ref & GD_REF_INDEX;
         t.state = (int)(1u | ((ref >> 27) & 14u));  // TRAV_LEAF, _ONE, _PAIR, _TRI1 or _TRIS (a leaf with more than two primitives keeps all three bits clear)
     } else {
         t.node = ref;
-        t.entry = entry;
         t.state = TRAV_DESCEND;
     }
 }
 
 /// Returns to the nearest pending upper child that is still worth visiting (or finishes).
+/// `band`: 1 in the reference's order; GD_NEAREST_BAND in an ordered NEAREST walk, whose entries are path maxima (trav_step_box).
 template <bool COUNT>
-GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true) {
+GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true, float band = 1.0f) {
+    const float limit = t.closest * band;  // (x 1.0f is exact)
     for (;;) {
         if (st.sp == 0) { t.state = TRAV_DONE; return; }
         StackEntry e = st.pop(writer);
-        if (e.pe > t.closest) continue;   // the reference's parent re-test fails: skip the upper child
+        if (e.pe > limit) continue;       // the reference's parent re-test fails: skip the upper child
         if (COUNT) wc->nodes++;           // the reference tests the upper child's box now
-        if (e.he > t.closest) continue;   // box missed (GD_ENTRY_MISS), or entered beyond the closest hit
+        if (e.he > limit) continue;       // box missed (GD_ENTRY_MISS), or entered beyond the closest hit
         trav_enter(t, e.ref, e.he);
         return;
     }
 }
 
+/// The band of a lane's walk: GD_NEAREST_BAND if it visits the nearer child first (`ordered`), 1 in the reference's order.
+GD_FN float trav_band(bool ordered) { return ordered ? GD_NEAREST_BAND : 1.0f; }
+
+/// A NEAREST walk has just finished (state DONE): removes the bookkeeping bit from the result and says whether the query must
+/// be walked again in the reference's order (trav_init, then steps with band 1): its winner is loose and a runner-up lies
+/// within the band — the one constellation in which the reference's order can have made another primitive win by rounding —,
+/// or the winner is adrift of its boxes by more than the band (a primitive whose computed parameter is far off: the reference
+/// may have pruned it whatever else it held), or the walk met an odd box (aabb_entry: second = -inf), whose entry parameter
+/// says nothing about what is inside.
+template <bool NEAREST>
+GD_FN bool trav_settle(Trav &t, bool ordered) {
+    if (!NEAREST) return false;
+    const bool hit = (int)t.hit_prim >= 0;
+    const bool again = ordered & ((t.second < 0) | (hit & (((t.hit_prim & GD_PRIM_ADRIFT) != 0) |
+                                                          (((t.hit_prim & GD_PRIM_LOOSE) != 0) & (t.second <= t.closest * GD_NEAREST_BAND)))));
+    t.hit_prim = hit ? (t.hit_prim & ~GD_PRIM_FLAGS) : t.hit_prim;
+    return again;
+}
+
 template <int BOXES = GD_BOXES_RUNTIME>
 GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool count) {
     t.closest = 1e+19f;
+    t.second = 1e+19f;
     t.hit_prim = GD_NO_PRIM;
     t.node = 0;
     t.entry = 0;
@@ -549,10 +602,12 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
 
 /// One interior-node visit: fetch its record, test both children's boxes, descend / stack / pop.
 /// Precondition: state == DESCEND.
-/// NEAREST (fast kernels, regular boxes): the child whose box is entered first is visited first (`order` = false keeps this
-/// lane's query in the reference's order, e.g. a Sun-shadow query). Both box tests of the record then count as performed.
+/// NEAREST (fast kernels, regular boxes): the child whose box is entered first is visited first, its entry parameter raised to
+/// the largest one on the path (what take_hit / trav_pop compare) and pruning widened by the band; `ordered` = false keeps this
+/// lane's query in the reference's order to the letter (a Sun-shadow query, a query trav_settle sent round again). Both box
+/// tests of the record count as performed.
 template <bool COUNT, int BOXES = GD_BOXES_RUNTIME, bool NEAREST = false>
-GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool order = true) {
+GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool ordered = true) {
     static_assert(!NEAREST || BOXES == GD_BOXES_FAST, "nearest-first walks are for trees of regular boxes");
     const float4 *rec = sc.recs + 4 * (size_t)t.node;
     float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
@@ -588,6 +643,12 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     if (BOXES == GD_BOXES_EXACT || (BOXES == GD_BOXES_RUNTIME && sc.exact_boxes)) {  // trees with an irregular box (wild input) only
         hl = aabb_entry<true>(r, rdiv, xyz(q0), xyz(q1), el);
         hh = aabb_entry<true>(r, rdiv, xyz(q2), xyz(q3), eh);
+    } else if (NEAREST) {
+        bool ol, oh;
+        hl = aabb_entry<false, true>(r, rdiv, xyz(q0), xyz(q1), el, &ol);
+        hh = aabb_entry<false, true>(r, rdiv, xyz(q2), xyz(q3), eh, &oh);
+        // a box whose entry parameter is not its slab entry: this query's answer may hinge on the visiting order (trav_settle)
+        t.second = (ordered & (ol | oh)) ? -__builtin_inff() : t.second;
     } else {
         hl = aabb_entry(r, rdiv, xyz(q0), xyz(q1), el);
         hh = aabb_entry(r, rdiv, xyz(q2), xyz(q3), eh);
@@ -600,20 +661,24 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     if (NEAREST) {
         uint32_t ref_n = __float_as_uint(q0.w), ref_f = __float_as_uint(q1.w);
         float en = hl ? el : GD_ENTRY_MISS, ef = hh ? eh : GD_ENTRY_MISS;
-        if (order && ef < en) {  // (equal entries, both origins inside included: lower child first, as the reference)
+        if (ordered && ef < en) {  // (equal entries, both origins inside included: lower child first, as the reference)
             const uint32_t rr = ref_n; ref_n = ref_f; ref_f = rr;
             const float ee = en; en = ef; ef = ee;
         }
+        // an ordered walk carries the largest entry parameter of the path (t.entry is this node's)
+        const float up = ordered ? t.entry : -__builtin_inff();
+        en = fmaxf(en, up); ef = fmaxf(ef, up);
+        const float band = trav_band(ordered);
         if (ef != GD_ENTRY_MISS) {
             StackEntry e;
             e.ref = ref_f; e.pe = t.entry; e.he = ef;
             st.push(e);
         }
-        if (!(en > t.closest)) {  // (GD_ENTRY_MISS is beyond every closest)
+        if (!(en > t.closest * band)) {  // (GD_ENTRY_MISS is beyond every closest)
             trav_enter(t, ref_n, en);
             return;
         }
-        trav_pop<false>(t, st, wc);
+        trav_pop<false>(t, st, wc, true, band);
         return;
     }
     if (COUNT || hh) {
@@ -630,19 +695,19 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
 
 /// Tests the primitives of the pending leaf, then pops. Precondition: state == LEAF or LEAF_TRIS.
 template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES, bool NEAREST = false>
-GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc) {
+GD_FN void trav_step_leaf(const Scene &sc, const Ray &r, Trav &t, TravStack &st, WorkCounters *wc, bool ordered = true) {
     bool stop;
     // (the triangle-mesh kernels keep the loop for their few other leaves — the floor disc —: the pair path there costs the
     // closest-hit launches 2 % for nothing)
     constexpr bool SMALL_PATH = (TYPES & 0xF) != ((1 << P_DISC) | (1 << P_TRIANGLE));
-    if (t.state & 8) stop = leaf_test_tris<ANY_HIT, COUNT, NEAREST>(sc, r, t.node, t.state == TRAV_LEAF_TRIS, t.closest, t.hit_prim, wc);
-    else if (SMALL_PATH && t.state != TRAV_LEAF) stop = leaf_test_small<ANY_HIT, COUNT, TYPES, NEAREST>(sc, r, t.node, t.state == TRAV_LEAF_PAIR, t.closest, t.hit_prim, wc);
-    else stop = leaf_test<ANY_HIT, COUNT, TYPES, NEAREST>(sc, r, t.node, t.closest, t.hit_prim, wc);
+    if (t.state & 8) stop = leaf_test_tris<ANY_HIT, COUNT, NEAREST>(sc, r, t.node, t.state == TRAV_LEAF_TRIS, t, wc);
+    else if (SMALL_PATH && t.state != TRAV_LEAF) stop = leaf_test_small<ANY_HIT, COUNT, TYPES, NEAREST>(sc, r, t.node, t.state == TRAV_LEAF_PAIR, t, wc);
+    else stop = leaf_test<ANY_HIT, COUNT, TYPES, NEAREST>(sc, r, t.node, t, wc);
     if (stop && ANY_HIT) {
         t.state = TRAV_DONE;
         return;
     }
-    trav_pop<COUNT && !NEAREST>(t, st, wc);
+    trav_pop<COUNT && !NEAREST>(t, st, wc, true, NEAREST ? trav_band(ordered) : 1.0f);
 }
 
 // ---- thin-wave modes: M = 2 or 4 lanes per ray ----------------------------------------------------------------------
@@ -698,7 +763,7 @@ GD_FN void thin_fetch(const Scene &sc, const Trav &t, uint32_t sub, ThinFetch &p
 /// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them), on the parts of the record the
 /// replicas hold in `pf` (thin_fetch). Precondition: DESCEND.
 template <int M, bool NEAREST = false>
-GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, bool order = true) {
+GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, bool ordered = true) {
     const float INF = __builtin_inff();
     float e;  // this lane's box: entry parameter, GD_ENTRY_MISS when not hit
     uint32_t ref_lo, ref_hi;
@@ -706,28 +771,48 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         const float4 mine = pf.a;
         const F3 other = f3(quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.x), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.y), quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(mine.z));
         const bool inside = within(ro.x, mine.x, other.x) & within(ro.y, mine.y, other.y) & within(ro.z, mine.z, other.z);
-        const float cx = face_candidate((mine.x - ro.x) * rdiv.x, ro.y, rd.y, mine.y, other.y, ro.z, rd.z, mine.z, other.z);
-        const float cy = face_candidate((mine.y - ro.y) * rdiv.y, ro.x, rd.x, mine.x, other.x, ro.z, rd.z, mine.z, other.z);
-        const float cz = face_candidate((mine.z - ro.z) * rdiv.z, ro.x, rd.x, mine.x, other.x, ro.y, rd.y, mine.y, other.y);
+        const float kx = (mine.x - ro.x) * rdiv.x, ky = (mine.y - ro.y) * rdiv.y, kz = (mine.z - ro.z) * rdiv.z;
+        const float cx = face_candidate(kx, ro.y, rd.y, mine.y, other.y, ro.z, rd.z, mine.z, other.z);
+        const float cy = face_candidate(ky, ro.x, rd.x, mine.x, other.x, ro.z, rd.z, mine.z, other.z);
+        const float cz = face_candidate(kz, ro.x, rd.x, mine.x, other.x, ro.y, rd.y, mine.y, other.y);
         const float half = fminf(fminf(cx, cy), cz);
         const float best = fminf(half, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(half));
         e = inside ? -1.0f : fminf(best, 1.0e+19f);
         e = (inside | (best < INF)) ? e : GD_ENTRY_MISS;
+        if (NEAREST) {  // aabb_entry's `odd`: the box is entered beyond its slab entry (the partner lane holds the other plane of every axis)
+            const float slab = fmaxf(fmaxf(fminf(kx, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(kx)), fminf(ky, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(ky))),
+                                     fminf(kz, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(kz)));
+            const uint32_t odd = (!inside & (best < INF) & (best > slab)) ? 1u : 0u;
+            if (ordered & ((odd | quad_u<GD_QUAD_PERM(2, 3, 0, 1)>(odd)) != 0)) t.second = -INF;
+        }
         ref_lo = quad_u<GD_QUAD_PERM(0, 0, 0, 0)>(__float_as_uint(mine.w));
         ref_hi = quad_u<GD_QUAD_PERM(1, 1, 1, 1)>(__float_as_uint(mine.w));
     } else {
         const float4 bmin = pf.a, bmax = pf.b;
         float pos;
-        const bool hit = aabb_entry(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos);
+        bool hit;
+        if (NEAREST) {
+            bool odd_box;
+            hit = aabb_entry<false, true>(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos, &odd_box);
+            const uint32_t odd = odd_box ? 1u : 0u;
+            if (ordered & ((odd | quad_u<GD_QUAD_PERM(1, 0, 3, 2)>(odd)) != 0)) t.second = -INF;
+        } else
+            hit = aabb_entry(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos);
         e = hit ? pos : GD_ENTRY_MISS;
         ref_lo = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmin.w));
         ref_hi = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmax.w));
     }
     float el = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(e) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(e);
     float eh = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(e) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(e);
-    if (NEAREST && order && eh < el) {  // the upper child's box is entered first (GD_ENTRY_MISS is the largest value): it goes first
+    if (NEAREST && ordered && eh < el) {  // the upper child's box is entered first (GD_ENTRY_MISS is the largest value): it goes first
         const uint32_t rr = ref_lo; ref_lo = ref_hi; ref_hi = rr;
         const float ee = el; el = eh; eh = ee;
+    }
+    float band = 1.0f;
+    if (NEAREST) {  // as trav_step_box: path maxima and the band in an ordered walk
+        const float up = ordered ? t.entry : -INF;
+        el = fmaxf(el, up); eh = fmaxf(eh, up);
+        band = trav_band(ordered);
     }
     const bool writer = sub == 0;
     if (eh != GD_ENTRY_MISS) {
@@ -735,25 +820,25 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         s.ref = ref_hi; s.pe = t.entry; s.he = eh;
         st.push(s, writer);
     }
-    if (el != GD_ENTRY_MISS && !(el > t.closest)) {
+    if (el != GD_ENTRY_MISS && !(el > t.closest * band)) {
         trav_enter(t, ref_lo, el);
         return;
     }
-    trav_pop<false>(t, st, nullptr, writer);
+    trav_pop<false>(t, st, nullptr, writer, band);
 }
 
 /// The same, fetching the record itself (the loops that do not fetch ahead).
 template <int M, bool NEAREST = false>
-GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, bool order = true) {
+GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, bool ordered = true) {
     ThinFetch pf;
     thin_fetch<M>(sc, t, sub, pf);
-    trav_step_box_thin_on<M, NEAREST>(ro, rd, rdiv, t, st, sub, pf, order);
+    trav_step_box_thin_on<M, NEAREST>(ro, rd, rdiv, t, st, sub, pf, ordered);
 }
 
 /// The pending leaf of a ray carried by M replicas, then the pop. A leaf of one or two triangles is split between the halves
 /// of the group (its triangle in `pf`, thin_fetch); every other leaf runs replicated through the code of `trav_step_leaf`.
 template <int M, int TYPES, bool NEAREST = false>
-GD_FN void trav_step_leaf_thin_on(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf) {
+GD_FN void trav_step_leaf_thin_on(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, bool ordered = true) {
     const bool writer = sub == 0;
     constexpr bool SMALL_PATH = (TYPES & 0xF) != ((1 << P_DISC) | (1 << P_TRIANGLE));
     const Ray r{ro, rd};
@@ -763,34 +848,40 @@ GD_FN void trav_step_leaf_thin_on(const Scene &sc, F3 ro, F3 rd, Trav &t, TravSt
         const float ta = M == 4 ? quad_f<GD_QUAD_PERM(0, 0, 0, 0)>(tt) : quad_f<GD_QUAD_PERM(0, 0, 2, 2)>(tt);
         float tb = M == 4 ? quad_f<GD_QUAD_PERM(2, 2, 2, 2)>(tt) : quad_f<GD_QUAD_PERM(1, 1, 3, 3)>(tt);
         tb = two ? tb : -1.0f;
-        if (ta > 0 && closer<NEAREST>(ta, t.node, t.closest, t.hit_prim)) { t.closest = ta; t.hit_prim = t.node; }
-        if (tb > 0 && closer<NEAREST>(tb, t.node + 1, t.closest, t.hit_prim)) { t.closest = tb; t.hit_prim = t.node + 1; }
+        take_hit<NEAREST>(t, ta, t.node);
+        take_hit<NEAREST>(t, tb, t.node + 1);
     } else if (SMALL_PATH && t.state != TRAV_LEAF) {
-        leaf_test_small<false, false, TYPES, NEAREST>(sc, r, t.node, t.state == TRAV_LEAF_PAIR, t.closest, t.hit_prim, nullptr);
+        leaf_test_small<false, false, TYPES, NEAREST>(sc, r, t.node, t.state == TRAV_LEAF_PAIR, t, nullptr);
     } else {
-        leaf_test<false, false, TYPES, NEAREST>(sc, r, t.node, t.closest, t.hit_prim, nullptr);
+        leaf_test<false, false, TYPES, NEAREST>(sc, r, t.node, t, nullptr);
     }
-    trav_pop<false>(t, st, nullptr, writer);
+    trav_pop<false>(t, st, nullptr, writer, NEAREST ? trav_band(ordered) : 1.0f);
 }
 
 template <int M, int TYPES, bool NEAREST = false>
-GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub) {
+GD_FN void trav_step_leaf_thin(const Scene &sc, F3 ro, F3 rd, Trav &t, TravStack &st, uint32_t sub, bool ordered = true) {
     ThinFetch pf;
     thin_fetch<M>(sc, t, sub, pf);  // (a state that is not a triangle leaf fetches nothing here)
-    trav_step_leaf_thin_on<M, TYPES, NEAREST>(sc, ro, rd, t, st, sub, pf);
+    trav_step_leaf_thin_on<M, TYPES, NEAREST>(sc, ro, rd, t, st, sub, pf, ordered);
 }
 
 /// Runs one query to completion (megakernels and test hooks).
-/// NEAREST: the fast kernels' order (the caller guarantees regular boxes), for the test hook that pins that walk to the fixtures.
+/// NEAREST: the fast kernels' walk (the caller guarantees regular boxes) including its second walk in the reference's order
+/// where trav_settle asks for one — for the test hook that pins that walk to the fixtures.
 template <bool ANY_HIT, bool COUNT, bool NEAREST = false>
 GD_FN void traverse(const Scene &sc, const Ray &r, TravStack &st, float &closest, uint32_t &hit_prim, WorkCounters *wc) {
     F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
     Trav t;
     constexpr int BOXES = NEAREST ? GD_BOXES_FAST : GD_BOXES_RUNTIME;
-    trav_init<BOXES>(sc, r, rdiv, t, st, wc, COUNT);
-    while (t.state != TRAV_DONE) {
-        if (t.state == TRAV_DESCEND) trav_step_box<COUNT, BOXES, NEAREST>(sc, r, rdiv, t, st, wc);
-        else trav_step_leaf<ANY_HIT, COUNT, GD_ALL_TYPES, NEAREST>(sc, r, t, st, wc);
+    bool ordered = true;
+    for (;;) {
+        trav_init<BOXES>(sc, r, rdiv, t, st, wc, COUNT && ordered);
+        while (t.state != TRAV_DONE) {
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, BOXES, NEAREST>(sc, r, rdiv, t, st, wc, ordered);
+            else trav_step_leaf<ANY_HIT, COUNT, GD_ALL_TYPES, NEAREST>(sc, r, t, st, wc, ordered);
+        }
+        if (!trav_settle<NEAREST>(t, ordered)) break;
+        ordered = false;
     }
     closest = t.closest;
     hit_prim = t.hit_prim;

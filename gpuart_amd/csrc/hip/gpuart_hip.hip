@@ -114,7 +114,8 @@ struct gpuart_hip_ctx {
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
     bool chunk_from_env = false;  ///< GPUART_HIP_CHUNK was given: no per-launch choice of the chunk size
-    uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box (converter.h): box tests take the comparison form
+    uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box, or a box that does not bound what it holds (converter.h):
+                                  ///< box tests take the comparison form and every walk keeps the reference's order
     uint32_t max_depth = 0;
     float4 *d_direct = nullptr, *d_accum = nullptr;
     unsigned long long *d_counters = nullptr;
@@ -478,7 +479,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     if ((r = upload_vec(c, c->d_prims, cv.prims))) return r;
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
     c->root_ref = root.ref;
-    c->exact_boxes = cv.irregular ? 1u : 0u;
+    c->exact_boxes = (cv.irregular || cv.disorderly) ? 1u : 0u;
     c->type_mask = cv.type_mask;
     c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
@@ -831,6 +832,7 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
         out->segments = h[6];
         out->box_steps = h[7];
         out->box_steps_top = h[8];
+        out->rewalks = h[9];
     }
     if (reset) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
     return 0;
@@ -1289,7 +1291,7 @@ int gpuart_hip_test_aabb(gpuart_hip_ctx *c, const float *rs, const float *rd, co
 int gpuart_hip_test_traverse(gpuart_hip_ctx *c, const float *rs, const float *rd, const float us[4], int n, int any_hit,
                              float *out0, float *out1) {
     if (!c || !c->have_scene || !us) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
-    if (any_hit == 2 && c->exact_boxes) return fail(GPUART_HIP_ERR_ARG, "a tree with irregular boxes is only walked in the reference's order");
+    if (any_hit == 2 && c->exact_boxes) return fail(GPUART_HIP_ERR_ARG, "a tree with irregular boxes (or boxes that do not bound their contents) is only walked in the reference's order");
     Float4Arg a; memcpy(a.v, us, 16);
     Scene sc = scene_of(c);
     const float *ins[] = {rs, rd}; float *outs[] = {out0, out1};

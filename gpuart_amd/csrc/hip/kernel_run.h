@@ -36,7 +36,8 @@
 #define RUN_RQ 512                  ///< capacity of a wave's ready list (at most two entries per live path)
 #endif
 #define RUN_SQ 128                  ///< capacity of a wave's shade list
-#define RUN_SLOT 0x1fffffffu        ///< entry: path slot (pass x pixel slot)
+#define RUN_SLOT 0x0fffffffu        ///< entry: path slot (pass x pixel slot)
+#define RUN_F_REWALK 0x10000000u    ///< (lane only) the query is on its second walk, in the reference's order (device_scene.h trav_settle)
 #define RUN_F_SHADOW 0x80000000u    ///< entry: the Sun-shadow query of the segment just shaded (else: the closest-hit query of the next one)
 #define RUN_F_JOIN 0x40000000u      ///< the path's other query is under way too: the last of the two to finish hands the path on
 #define RUN_F_FRESH 0x20000000u     ///< the path has not been shaded yet: segment 0, colorWeight 1, pathColor 0
@@ -106,7 +107,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     const uint32_t total = b.n_slots * b.batch;  // a multiple of 64: one chunk = 64 consecutive path slots (few pixels x the run's passes)
     const bool no_segments = !(P.maxSegments > 0 && 1.0f > P.minWeight);
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
     uint32_t segments = 0;
 
     // wave-uniform bookkeeping
@@ -127,7 +128,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     // per-lane query state
     uint32_t ent = SLOT_INVALID;            // the entry this lane works on (slot | flags), SLOT_INVALID: none
     F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0), rdiv = f3(1, 1, 1);
-    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
+    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0; t.second = 0;
 
 #ifdef GD_RUN_TIMELINE
     unsigned long long tl_start = wall_clock64(), tl_dry = 0, tl_lanes = 0, tl_rounds = 0, tl_prev = tl_start, tl_nready = 0, tl_nshade = 0;
@@ -140,6 +141,12 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
     for (;;) {
         bool start = false;  // this lane begins a query in this round
+        // ---- a finished nearest-first query that cannot vouch for its answer walks again, in the reference's order (every replica alike)
+        if (NEAR && ent != SLOT_INVALID && t.state == TRAV_DONE && trav_settle<NEAR>(t, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)))) {
+            ent |= RUN_F_REWALK;
+            if (COUNT) wc.rewalks++;
+            trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
+        }
         // ---- RETIRE: lanes whose query has finished --------------------------------------------------------------
         // (n_shade <= 63 here, see PRODUCE, so up to 64 appends fit the shade list)
         {
@@ -354,13 +361,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
 #if RUN_PIPE
                     if (t.state == TRAV_DESCEND) {
-                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, GD_NEAREST_SHADOW || !(ent & RUN_F_SHADOW));
+                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
                         thin_fetch<W>(sc, t, sub, pf);
                         fresh = (t.state & 8) != 0;
                     }
                     const bool leaf_now = (t.state & 1) != 0 && !fresh;
 #else
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, GD_NEAREST_SHADOW || !(ent & RUN_F_SHADOW));
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
                     const bool leaf_now = (t.state & 1) != 0;
 #endif
 #ifdef GD_RUN_TIMELINE
@@ -375,9 +382,9 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
                         if (leaf_now) {
 #if RUN_PIPE
-                            trav_step_leaf_thin_on<W, TYPES, NEAR>(sc, ro, rd, t, st, sub, pf);
+                            trav_step_leaf_thin_on<W, TYPES, NEAR>(sc, ro, rd, t, st, sub, pf, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
 #else
-                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub);
+                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
 #endif
                             if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
 #if RUN_PIPE
@@ -407,13 +414,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
             else thin_rounds(std::integral_constant<int, 4>());
         } else
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, GD_NEAREST_SHADOW || !(ent & RUN_F_SHADOW));
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
-                    trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                    trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
                     if (!REFWORK && (ent & RUN_F_SHADOW) && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                 }

@@ -68,8 +68,8 @@ GD_FN uint32_t slot_pixel_slot(const PathBuffers &b, uint32_t slot) { return slo
 
 GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned long long *g) {
     // one atomic per counter per wavefront
-    uint32_t v[9] = {wc.rays, wc.nodes, wc.prims[0], wc.prims[1], wc.prims[2], wc.prims[3], segments, wc.steps, wc.steps_top};
-    for (int k = 0; k < 9; k++) {
+    uint32_t v[10] = {wc.rays, wc.nodes, wc.prims[0], wc.prims[1], wc.prims[2], wc.prims[3], segments, wc.steps, wc.steps_top, wc.rewalks};
+    for (int k = 0; k < 10; k++) {
         unsigned long long s = v[k];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane_id() == 0 && s) atomicAdd(&g[k], s);
@@ -122,7 +122,7 @@ GD_FN void thin_regroup(uint32_t to, unsigned long long flying, uint32_t *xfer, 
     rd = f3(__shfl(rd.x, src, 64), __shfl(rd.y, src, 64), __shfl(rd.z, src, 64));
     rdiv = f3(__shfl(rdiv.x, src, 64), __shfl(rdiv.y, src, 64), __shfl(rdiv.z, src, 64));
     t.closest = __shfl(t.closest, src, 64); t.hit_prim = __shfl(t.hit_prim, src, 64); t.node = __shfl(t.node, src, 64);
-    t.entry = __shfl(t.entry, src, 64); t.state = __shfl(t.state, src, 64);
+    t.entry = __shfl(t.entry, src, 64); t.state = __shfl(t.state, src, 64); t.second = __shfl(t.second, src, 64);
     uint32_t sp = __shfl(st.sp, src, 64), base = __shfl(st.base, src, 64);
     if (!holds) { t.state = TRAV_DONE; sp = 0; base = 0; }
     // Columns, row by row: the loads of a row are one instruction of the whole wave and precede its stores, and a column that
@@ -243,7 +243,8 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     // Thin-wave modes (device_scene.h): once the queue is empty and the wave is down to 32 (16) rays, pairs (quads) of lanes carry
     // them. Not in the counting variant (its counters are per lane) nor for trees with irregular boxes.
     constexpr bool THIN_OK = GD_TRACE_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
-    // closest-hit queries enter the nearer child first (device_scene.h, GD_NEAREST): same answer, fewer node visits
+    // closest-hit queries enter the nearer child first (device_scene.h, GD_NEAREST): fewer node visits; a query whose answer that
+    // walk cannot certify goes round again in the reference's order (`refwalk`)
     constexpr bool NEAR = GD_NEAREST && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
     uint32_t M = 1, sub = 0;  // M wave-uniform
     const uint32_t *queue_c = b.queue[seg_c & 1];
@@ -251,7 +252,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     const uint32_t n = n_c + (seg_s >= 0 ? b.counters[4 * seg_s + 2] : 0u);
     uint32_t *cursor = &b.counters[seg_c >= 0 ? 4 * seg_c + 1 : 4 * seg_s + 3];
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
 
     // The first chunk of every wave is static (chunk index = workgroup index); later chunks come from the
     // shared cursor, which therefore starts behind the static ones. No atomic at all for small queues.
@@ -260,9 +261,10 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     bool exhausted = false;                                                                                   // wave-uniform
     uint32_t slot = SLOT_INVALID;
     bool shadow = false;                    // this lane's ray is a Sun-shadow query
+    bool refwalk = false;                   // this lane's query is on its second walk, in the reference's order
     F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0);  // the ray (two F3 locals: a long-lived Ray aggregate ends up in scratch)
     F3 rdiv = f3(1, 1, 1);
-    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
+    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0; t.second = 0;
 
     for (;;) {
         // ---- refill idle lanes from the queue
@@ -286,6 +288,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                 if (s != SLOT_INVALID) {
                     slot = s;
                     shadow = sh;
+                    refwalk = false;
                     ro = xyz(b.ray_o[s]);
                     rd = sh ? sun : xyz(b.ray_d[s]);
                     rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
@@ -305,11 +308,11 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             const uint32_t left = (uint32_t)__popcll(flying);
             const uint32_t to = left <= BLOCK / 4 && GD_TRACE_THIN >= 4 ? 4u : left <= BLOCK / 2 ? 2u : 1u;
             if (to > M) {
-                uint32_t sh = shadow ? 1u : 0u;
+                uint32_t sh = (shadow ? 1u : 0u) | (refwalk ? 2u : 0u);
                 // (the stack ring doubles as the scratch of the move: row 0 is copied first, and the table is read before that)
                 __shared__ uint32_t xfer[BLOCK];
                 thin_regroup(to, flying, xfer, ring_a, ring_b, spill, slot, sh, ro, rd, rdiv, t, st);
-                shadow = sh != 0;
+                shadow = (sh & 1u) != 0; refwalk = (sh & 2u) != 0;
                 if ((uint32_t)lane_id() / to >= left) slot = SLOT_INVALID;
                 M = to;
                 sub = (uint32_t)lane_id() & (M - 1);
@@ -321,13 +324,13 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, GD_NEAREST_SHADOW || !shadow);
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, !shadow && !refwalk);
                     const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
                     if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
                         if (t.state & 1) {
-                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub);
+                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub, !shadow && !refwalk);
                             if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                         }
                         busy = __ballot(t.state != TRAV_DONE) & LEAD;
@@ -342,7 +345,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         } else
         // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, GD_NEAREST_SHADOW || !shadow);
+            if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, !shadow && !refwalk);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             // leaves are tested once 1/leaf_share of the lanes that still have a ray wait at one (at most leaf_lanes):
@@ -350,7 +353,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
-                    trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr);
+                    trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr, !shadow && !refwalk);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
                     if (shadow && any_shadow && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;
                 }
@@ -362,6 +365,11 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             if (!exhausted && 64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
             // a draining wave may move to pairs / quads once it is down to 32 rays
             if (THIN_OK && exhausted && (uint32_t)__popcll(busy) <= BLOCK / 2) break;
+        }
+        // ---- a finished nearest-first query that cannot vouch for its answer walks again, in the reference's order (every replica alike)
+        if (NEAR && slot != SLOT_INVALID && t.state == TRAV_DONE && trav_settle<NEAR>(t, !shadow && !refwalk)) {
+            refwalk = true;
+            trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
         }
         // ---- retire finished rays (a ray's first replica retires it)
         if (slot != SLOT_INVALID && t.state == TRAV_DONE && (!THIN_OK || sub == 0)) {
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
       __syncthreads();
     }
     if (REFWORK) {
-        WorkCounters z = {0, 0, {0, 0, 0, 0}, 0, 0};
+        WorkCounters z = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
         flush_counters(z, segments, gcounters);
     }
 }
@@ -463,7 +471,7 @@ __global__ void __launch_bounds__(BLOCK) k_direct(Scene sc, Frame f, gpuart_para
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;
         if (!slot_pixel(f, slot, lx, ly)) continue;
@@ -510,14 +518,16 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
     bool exhausted = false;                                                                                   // wave-uniform
     uint32_t pixel = SLOT_INVALID;          // index into `out` of the pixel this lane works on
     int stage = DL_PRIMARY, bounce = 0;
+    bool refwalk = false;                   // this lane's query is on its second walk, in the reference's order (trav_settle)
     F3 ro = f3(0, 0, 0), rd = f3(1, 0, 0), rdiv = f3(1, 1, 1);
     F3 cw = f3(1, 1, 1), acc = f3(0, 0, 0), sun_term = f3(0, 0, 0), em_term = f3(0, 0, 0), em_dir = f3(0, 0, 0), ambient = f3(0, 0, 0);
     float em_dist = 0;
-    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0;
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
+    Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0; t.second = 0;
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
 
     auto start_query = [&](F3 o, F3 d) {
         ro = o; rd = d;
+        refwalk = false;
         rdiv = f3(1 / d.x, 1 / d.y, 1 / d.z);
         trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
     };
@@ -562,10 +572,10 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
             const uint32_t to = left <= BLOCK / 4 && GD_TRACE_THIN >= 4 ? 4u : left <= BLOCK / 2 ? 2u : 1u;
             if (to > M) {
                 __shared__ uint32_t xfer[BLOCK];
-                uint32_t tag = (uint32_t)stage | ((uint32_t)bounce << 8);
+                uint32_t tag = (uint32_t)stage | ((uint32_t)bounce << 8) | (refwalk ? 1u << 16 : 0u);
                 int src = lane_id();
                 thin_regroup(to, flying, xfer, ring_a, ring_b, spill, pixel, tag, ro, rd, rdiv, t, st, &src);
-                stage = (int)(tag & 255u); bounce = (int)(tag >> 8);
+                stage = (int)(tag & 255u); bounce = (int)((tag >> 8) & 255u); refwalk = (tag >> 16) != 0;
                 // the pixel's pending terms travel with it
                 auto move3 = [&](F3 &v) { v = f3(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)); };
                 move3(cw); move3(acc); move3(sun_term); move3(em_term); move3(em_dir); move3(ambient);
@@ -581,13 +591,13 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, GD_NEAREST_SHADOW || stage != DL_SUN);
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, stage != DL_SUN && !refwalk);
                     const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
                     const uint32_t waiting = (uint32_t)__popcll(at_leaf);
                     if (at_leaf && (W * waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= (uint32_t)__popcll(busy))) {
                         if (t.state & 1) {
-                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub);
+                            trav_step_leaf_thin<W, TYPES, NEAR>(sc, ro, rd, t, st, sub, stage != DL_SUN && !refwalk);
                             if (stage == DL_SUN && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;  // only "anything hit?" is asked
                         }
                         busy = __ballot(t.state != TRAV_DONE) & LEAD;
@@ -603,13 +613,13 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
         } else
         // ---- traverse until enough lanes have an answer (a lane without a pixel is in state DONE)
         for (;;) {
-            if (t.state == TRAV_DESCEND) trav_step_box<false, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, nullptr, GD_NEAREST_SHADOW || stage != DL_SUN);
+            if (t.state == TRAV_DESCEND) trav_step_box<false, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, nullptr, stage != DL_SUN && !refwalk);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
                 if (t.state & 1) {
-                    trav_step_leaf<false, false, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, nullptr);
+                    trav_step_leaf<false, false, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, nullptr, stage != DL_SUN && !refwalk);
                     if (stage == DL_SUN && t.hit_prim != GD_NO_PRIM) t.state = TRAV_DONE;  // only "anything hit?" is asked
                 }
                 descending = __ballot(t.state == TRAV_DESCEND);
@@ -618,6 +628,11 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
             unsigned long long busy = descending | at_leaf;
             if (!busy) break;
             if (64u - (uint32_t)__popcll(busy) >= tune.refill_lanes) break;
+        }
+        // ---- a finished nearest-first query that cannot vouch for its answer walks again, in the reference's order (device_scene.h)
+        if (NEAR && pixel != SLOT_INVALID && t.state == TRAV_DONE && trav_settle<NEAR>(t, stage != DL_SUN && !refwalk)) {
+            refwalk = true;
+            trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
         }
         // ---- lanes with an answer move their pixel on (direct_lighting.glsl:134-207); replicas do so identically (the one store
         //      of a finished pixel is the same value to the same address)
@@ -682,7 +697,7 @@ __global__ void __launch_bounds__(BLOCK) k_pt_mega(Scene sc, Frame f, gpuart_par
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
-    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0};
+    WorkCounters wc = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
     uint32_t segments = 0;
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n_slots; slot += gridDim.x * BLOCK) {
         uint32_t lx, ly;

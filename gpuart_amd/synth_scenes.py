@@ -226,6 +226,45 @@ def random_wild_case(seed):
     return case
 
 
+# third class (--lattice): geometry whose boxes are NOT conservative for their primitives in fp32 — coplanar, overlapping,
+# axis-aligned triangles and discs with all coordinates on a coarse lattice (z-fighting surfaces), coincident spheres. A flat
+# triangle's box has zero thickness, its entry parameter and the triangle's own hit parameter are the same number computed two
+# ways, a few ulps apart in either direction: which of two coincident surfaces the reference reports then hinges on the
+# order in which its walk meets them and on what it pruned in between. A walk in any other order has to notice (device_scene.h,
+# GD_NEAREST) — this class is what checks that it does.
+def lattice_prims(rs, n):
+    L = lambda lo, hi: f32(rs.randint(int(lo * 4), int(hi * 4) + 1) / 4.0)
+    prims = []
+    for _ in range(n):
+        kind = rs.rand()
+        if kind < 0.75:  # axis-aligned triangle: all three vertices share coordinate k
+            k = int(rs.randint(3))
+            v = [[L(-1, 1), L(-1, 1), L(0, 1.25)] for _ in range(3)]
+            c = L(0.25, 1.25) if k == 2 else L(-1, 1)
+            for q in v:
+                q[k] = c
+            prims.append((TRIANGLE, [x for q in v for x in q]))
+        elif kind < 0.9:  # axis-aligned disc on a lattice plane
+            k = int(rs.randint(3))
+            nrm = [0.0, 0.0, 0.0]; nrm[k] = float(rs.choice([-1, 1]))
+            prims.append((DISC, [L(-1, 1), L(-1, 1), L(0.25, 1.25), f32(nrm[0]), f32(nrm[1]), f32(nrm[2]), f32(rs.choice([0.25, 0.5, 0.75]))]))
+        else:  # spheres that coincide or touch
+            prims.append((SPHERE, [L(-1, 1), L(-1, 1), L(0.25, 1.0), f32(rs.choice([0.25, 0.5]))]))
+    return prims
+
+
+def lattice_scene(seed=3, n=400):
+    """A fixed scene of the lattice class for tools/order_soak.py (default camera)."""
+    return [(DISC, [0, 0, 0, 0, 0, 1, 6])] + lattice_prims(np.random.RandomState(seed), n)
+
+
+def random_lattice_case(seed):
+    case = random_case(seed)
+    rs = np.random.RandomState(3000017 + seed)
+    case["prims"] = ([(DISC, [0, 0, 0, 0, 0, 1, 6])] if rs.rand() < 0.7 else []) + lattice_prims(rs, int(rs.choice([2, 3, 8, 40, 200])))
+    return case
+
+
 # ---- stand-ins for the reference's two primitive-list scenes (data/cluster_100k.dat, data/tree1_21k.dat are absent) ----
 # Written in the dialect Utils::LoadPrimitives reads (src/utils.cpp:136-203): `sphere x y z [r]` (r defaults to 4) and
 # `cone x1 y1 z1 x2 y2 z2 r1 r2` lines, `#` comments; loaded as InitCluster / InitTree do (src/scenes.cpp:69-103).

@@ -62,6 +62,8 @@ typedef struct gpuart_counters {
     uint64_t segments;      /* path segments traced */
     uint64_t box_steps;     /* interior-node visits (one 64-byte record fetch each) */
     uint64_t box_steps_top; /* ... of nodes above level GPUART_HIP_TOP_DEPTH (environment, read at upload; diagnostic) */
+    uint64_t rewalks;       /* mode 4: closest-hit queries whose nearest-child-first walk could not certify its answer and that
+                             * were walked again in the reference's order (their second walk's nodes / primitives are counted) */
 } gpuart_counters;
 
 const char *gpuart_hip_last_error(void);

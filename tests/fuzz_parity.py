@@ -29,6 +29,9 @@ if RENDERER:
 WILD2 = "--wild2" in sys.argv  # the second class of hostile numbers (gpuart_amd.synth_scenes.random_wild2_case)
 if WILD2:
     sys.argv.remove("--wild2")
+LATTICE = "--lattice" in sys.argv  # coplanar / coincident primitives on a coarse lattice (gpuart_amd.synth_scenes.random_lattice_case)
+if LATTICE:
+    sys.argv.remove("--lattice")
 
 
 def main():
@@ -37,7 +40,7 @@ def main():
     be = B.Backend(0)
     bad = 0
     for seed in range(first, first + count):
-        case = S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
+        case = S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
         prims, W, H = case["prims"], case["W"], case["H"]
         cd = case["cam"]
         cam = O.camera(cd["pos"], cd["dir"], cd["up"], cd["fov_y"], cd["screen_dist"], W, H)
