@@ -61,6 +61,15 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #ifndef GD_NEAREST_BAND
 #define GD_NEAREST_BAND 1.00390625f  ///< 1 + 2^-8 (free up to 2^-8, +2.5 % time at 2^-6: profiles/r04/nearest_child_first.txt)
 #endif
+#ifndef GD_CERT_ODD
+#define GD_CERT_ODD 1      // ablation switches of the certificate's parts (tools/ab_build.sh; never 0 in the product build)
+#endif
+#ifndef GD_CERT_PATHMAX
+#define GD_CERT_PATHMAX 1
+#endif
+#ifndef GD_CERT_HITS
+#define GD_CERT_HITS 1
+#endif
 #define GD_PRIM_LOOSE 0x40000000u  ///< in Trav::hit_prim during a NEAREST walk: a box on the winner's path is entered beyond the winner's parameter
 #define GD_PRIM_ADRIFT 0x20000000u ///< ... beyond the winner's parameter x BAND: the parameter and its boxes disagree by more than rounding
 #define GD_PRIM_FLAGS (GD_PRIM_LOOSE | GD_PRIM_ADRIFT)
@@ -337,6 +346,11 @@ GD_FN bool take_hit(Trav &t, float pos, uint32_t pi) {
         return true;
     }
     const bool win = (pos < t.closest) | ((pos == t.closest) & ((int)pi < (int)(t.hit_prim & ~GD_PRIM_FLAGS)));
+    if (!GD_CERT_HITS) {
+        t.hit_prim = win ? pi : t.hit_prim;
+        t.closest = win ? pos : t.closest;
+        return win;
+    }
     t.second = fminf(t.second, win ? t.closest : pos);  // (second >= closest unless it is the -inf of an odd box, which sticks)
     t.hit_prim = win ? (pi | (t.entry > pos ? GD_PRIM_LOOSE : 0u) | (t.entry > pos * GD_NEAREST_BAND ? GD_PRIM_ADRIFT : 0u)) : t.hit_prim;
     t.closest = win ? pos : t.closest;
@@ -643,7 +657,7 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     if (BOXES == GD_BOXES_EXACT || (BOXES == GD_BOXES_RUNTIME && sc.exact_boxes)) {  // trees with an irregular box (wild input) only
         hl = aabb_entry<true>(r, rdiv, xyz(q0), xyz(q1), el);
         hh = aabb_entry<true>(r, rdiv, xyz(q2), xyz(q3), eh);
-    } else if (NEAREST) {
+    } else if (NEAREST && GD_CERT_ODD) {
         bool ol, oh;
         hl = aabb_entry<false, true>(r, rdiv, xyz(q0), xyz(q1), el, &ol);
         hh = aabb_entry<false, true>(r, rdiv, xyz(q2), xyz(q3), eh, &oh);
@@ -666,8 +680,10 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
             const float ee = en; en = ef; ef = ee;
         }
         // an ordered walk carries the largest entry parameter of the path (t.entry is this node's)
-        const float up = ordered ? t.entry : -__builtin_inff();
-        en = fmaxf(en, up); ef = fmaxf(ef, up);
+        if (GD_CERT_PATHMAX) {
+            const float up = ordered ? t.entry : -__builtin_inff();
+            en = fmaxf(en, up); ef = fmaxf(ef, up);
+        }
         const float band = trav_band(ordered);
         if (ef != GD_ENTRY_MISS) {
             StackEntry e;

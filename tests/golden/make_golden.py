@@ -572,6 +572,24 @@ def gen_traverse_wild(gl):
         save("traverse_wild_" + name, tree=tree, rs=rs, rd=rd, o0=o0, o1=o1)
 
 
+def gen_order_rays(gl):
+    """The rays of tests/golden/order_rays.npz (found on the GPU by tools/order_rays.py: closest-hit queries on which a walk in
+    another order than the reference's returned another primitive, because a box on the way reports an entry parameter beyond the
+    hits inside it) through the reference's CheckIntersectionInclUserSphere on llvmpipe: what the reference itself answers."""
+    body = ("float pos; vec3 p, n; int t; bool ush; CheckIntersectionInclUserSphere(i0.xyz, i1.xyz, BVH, i2, pos, p, n, t, ush);"
+            "if (t >= 0) { O0 = vec4(pos, p); O1 = vec4(n, float(t) + (ush ? 0.5 : 0.0)); } else { O0 = vec4(-1, 0, 0, 0); O1 = vec4(0, 0, 0, -1); }")
+    objs = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "common.glsl", "noise.glsl", "bvh_intersection.glsl", "intersection.glsl"]
+    g = dict(np.load(os.path.join(OUT, "order_rays.npz")))
+    for name, scene in (("cfg3", "scene_d"), ("tree", "tree")):
+        _, tree, _ = scene_tree(scene)
+        rs, rd = g[name + "_rs"], g[name + "_rd"]
+        us = np.zeros((len(rs), 4), np.float32)
+        o0, o1 = glref.run_probe_big(gl, body, objs, [pad4(rs), pad4(rd), us], 2, bvh=tree, decls=D_INCL, chunk=4096)
+        g[name + "_o0"], g[name + "_o1"] = o0, o1
+        print("order_rays %s:" % name, o0[:, 0], o1[:, 3])
+    save("order_rays", **g)
+
+
 def gen_traverse_leaves(gl):
     """CheckIntersectionInclUserSphere on trees with leaves of other sizes than the default build makes (minPrimitivesPerNode 5;
     depth limits 4, 6 and 1 = the whole scene in the root leaf): the device walks such leaves with its counting loop instead of
@@ -743,7 +761,7 @@ def gen_dragon871k(gl):
 
 
 SECTIONS = dict(dragon871k=gen_dragon871k, scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, order_rays=gen_order_rays, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

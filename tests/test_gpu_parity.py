@@ -254,28 +254,68 @@ def test_traversal_with_hostile_rays_and_trees(be, name):
             "nearer child first: " if nearest else "", int(bad.sum()), len(bad), int(np.nonzero(bad)[0][0]), g["rs"][bad][0], g["rd"][bad][0], got[bad][0], exp[bad][0])
 
 
-def deep_chain_scene(n=40):
+def deep_chain_scene(n=40, k0=0):
     """Spheres at x = 2^k: every split peels one sphere off -> tree depth n-1 > LDS stack depth."""
-    return [(S.SPHERE, [float(2.0 ** k), 0.0, 0.0, float(2.0 ** (k - 2))]) for k in range(n)]
+    return [(S.SPHERE, [float(2.0 ** k), 0.0, 0.0, float(2.0 ** (k - 2))]) for k in range(k0, k0 + n)]
 
 
-def test_deep_tree_spills_the_ring_stack(be, O):
-    prims = deep_chain_scene()
+@pytest.mark.parametrize("k0", [0, -20])
+def test_deep_tree_spills_the_ring_stack(be, O, B, k0):
+    """k0 = 0: coordinates up to 5e11 — beyond what the uploader lets the fast kernels walk in their own order (converter.h), so
+    the nearest-first hook is refused; k0 = -20: the same chain within 2^20, walked in both orders."""
+    prims = deep_chain_scene(40, k0)
     tree, depth = O.build_bvh(prims)
     assert depth > 16
     be.upload_bvh(tree)
     assert be.scene_info()["max_depth"] == depth
     rng = np.random.RandomState(5)
     n = 2048
-    rs = np.zeros((n, 4), np.float32); rs[:, 0] = -3; rs[:, 1:3] = rng.uniform(-1, 1, (n, 2))
-    tgt = np.zeros((n, 3)); k = rng.randint(0, 40, n); tgt[:, 0] = 2.0 ** k; tgt[:, 1:] = rng.normal(size=(n, 2)) * (2.0 ** (k - 2))[:, None]
+    sc = 2.0 ** k0
+    rs = np.zeros((n, 4), np.float32); rs[:, 0] = -3 * sc; rs[:, 1:3] = rng.uniform(-1, 1, (n, 2)) * sc
+    tgt = np.zeros((n, 3)); k = rng.randint(0, 40, n) + k0; tgt[:, 0] = 2.0 ** k; tgt[:, 1:] = rng.normal(size=(n, 2)) * (2.0 ** (k - 2))[:, None]
     rd = np.zeros((n, 4), np.float32); rd[:, :3] = tgt - rs[:, :3]
     e0, e1 = O.traverse(tree, rs, rd, S.USER_SPHERE)
     o0, o1 = be.test_traverse(rs, rd, S.USER_SPHERE)
     assert (e1[:, 3] >= 0).mean() > 0.3
     assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "closest hit through the spill path")
-    o0, o1 = be.test_traverse(rs, rd, S.USER_SPHERE, nearest_first=True)
-    assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "closest hit through the spill path, nearer child first")
+    if k0 == 0:
+        with pytest.raises(B.HipError, match="do not bound their contents"):
+            be.test_traverse(rs, rd, S.USER_SPHERE, nearest_first=True)
+    else:
+        o0, o1 = be.test_traverse(rs, rd, S.USER_SPHERE, nearest_first=True)
+        assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "closest hit through the spill path, nearer child first")
+
+
+def test_rays_on_which_visiting_order_decides(be, O):
+    """Four rays found by tools/order_rays.py among 1.7e9 (tests/golden/order_rays.npz): each meets a box whose entry parameter, as
+    the reference computes it, is NOT its slab entry — the face the ray enters through fails its own test by rounding at an
+    edge, and the running minimum falls on the face the ray leaves through. Such a box claims to be entered beyond hits that
+    lie inside it, and what the reference finds there depends on when its walk arrives. A nearest-first walk without the
+    certificate (device_scene.h: odd boxes) returned a hit 0.04 % to 3 % further away on each of them. Expected values: the
+    reference's own GLSL on llvmpipe."""
+    g = golden("order_rays")
+    for name, descs in (("cfg3", S.scene_d()), ("tree", S.tree_scene())):
+        tree, _ = O.build_bvh(descs)
+        be.upload_bvh(tree)
+        rs, rd = g[name + "_rs"], g[name + "_rd"]
+        e0, e1 = g[name + "_o0"], g[name + "_o1"]  # the reference's GLSL on llvmpipe (make_golden.py order_rays)
+        assert (e1[:, 3] >= 0).all()
+        for nearest in (False, True):
+            o0, o1 = be.test_traverse(rs, rd, (0, 0, 0, 0), nearest_first=nearest)
+            assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "%s rays, nearest first %s" % (name, nearest))
+
+
+@pytest.mark.parametrize("flavour,seed", [("--wild", 100138), ("--wild2", 101453), ("--wild2", 100145), ("--wild2", 101115)])
+def test_hostile_scenes_that_keep_the_reference_order(flavour, seed):
+    """Scenes of the hostile classes whose boxes are regular but do not bound what they hold in any useful sense — a triangle
+    with a vertex at -1e30 or +-1e19 (the intersector's `origin - v0` swallows the origin: its hit parameter is off by whole
+    units), negative radii — rendered wrongly by a nearest-first walk: the uploader finds them (converter.h prim_in_box)
+    and such a tree is walked in the reference's order throughout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), flavour, str(seed), "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "1 scenes, 0 with differences" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 # ---- frames -----------------------------------------------------------------------------------------
@@ -348,9 +388,12 @@ def test_other_execution_modes_give_identical_frames(B, be, O, name, mode):
         be.set_mode(0)
 
 
-def test_deep_tree_frames(B, be, O):
-    """A 39-level tree (deeper than the LDS ring stack): frames through the spill path == oracle."""
-    prims = deep_chain_scene() + [(S.DISC, [0, 0, -0.3, 0, 0, 1, 40])]
+@pytest.mark.parametrize("k0", [0, -19])
+def test_deep_tree_frames(B, be, O, k0):
+    """A 39-level tree (deeper than the LDS ring stack): frames through the spill path == oracle. k0 = 0: spheres out to 5e11,
+    which the uploader keeps in the reference's order (kernels without thin-wave modes); k0 = -19: the chain within 2^20, through
+    the fast kernels (nearer child first, thin-wave modes with partly spilled stacks)."""
+    prims = deep_chain_scene(40, k0) + [(S.DISC, [0, 0, -0.3, 0, 0, 1, 40])]
     tree, depth = O.build_bvh(prims)
     assert depth > 16
     W, H = 96, 64
@@ -742,6 +785,49 @@ def test_4k_and_8k_configs(B, O):
             assert_bits(acc[k:k + 8, x0:x0 + 64, :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "%dx%d window" % (W, H))
 
 
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_cfg4_and_cfg5_at_their_stated_depth(B, O, cfg):
+    """BASELINE.json's two deep configurations rendered to their full depth through the Renderer in its default mode, as
+    Renderer::RenderPathTracingPass accumulates them (reference src/renderer.cpp:534-616): cfg4 = Scene D, 3840x2160, 1024
+    progressive passes of 1 path per pixel (RestartPathTracing(1, 1024): 16 plan-sized runs of 64 passes); cfg5 = 7680x4320,
+    256 passes, share 5 of an 8-way split (what one of 8 GPUs renders). Three 64x8 windows of the accumulator — on the mesh,
+    on the floor, at the horizon — against the oracle accumulating the same 1024 / 256 RandSeeds, bit for bit."""
+    from gpuart_amd import sharding
+    W, H, passes, share = {"cfg4": (3840, 2160, 1024, None), "cfg5": (7680, 4320, 256, (5, 8))}[cfg]
+    cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
+    r = B.Renderer(W, H, cam)
+    r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
+    r.set_primitives(B.make_prims(S.scene_d()))
+    r.set_max_path_segments(8)
+    rows = np.arange(H)
+    if share:
+        y0, n, band, stride, rows = sharding.interleaved_rows(share[0], share[1], H)
+        assert r.set_interleaved_tile(0, y0, W, n, band, stride)
+    r.restart_path_tracing(1, passes)
+    done = [r.path_tracing_pass() for _ in range(passes)]
+    assert done == list(range(1, passes + 1)) and r.path_tracing_pass() == passes  # (one more call renders nothing)
+    acc = r.read_radiance(False)
+    norm = r.read_radiance(True)
+    r.close()
+    assert acc.shape == (len(rows), W, 4) and np.isfinite(acc[..., :3]).all() and acc[..., :3].min() >= 0
+    np.testing.assert_array_equal(norm[..., :3], acc[..., :3] / np.float32(passes))  # pt_normalize.glsl:44-47
+    tree, _ = O.build_bvh(S.scene_d())
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 8, 0.01)
+    seeds = O.randseeds(passes)
+    hits = 0
+    for fx, fy in ((0.5, 0.5), (0.3, 0.12), (0.7, 0.62)):  # mesh / floor / around the horizon (benchmark camera)
+        k = int(np.searchsorted(rows, int(fy * H))) // 8 * 8  # an 8-row group: contiguous frame rows in both layouts
+        gy, x0 = int(rows[k]), int(fx * W) // 8 * 8
+        exp = np.zeros((8, 64, 4), np.float32)
+        for sd in seeds:
+            O.pt_pass(tree, c, W, H, P, sd, 1, exp, tile=(x0, gy, 64, 8), nthreads=8)
+        assert_bits(acc[k:k + 8, x0:x0 + 64, :3].reshape(-1, 3), exp[..., :3].reshape(-1, 3), "%s window at (%d, %d) after %d passes" % (cfg, x0, gy, passes))
+        hits += 1
+    assert hits == 3
+
+
 def test_full_size_accumulation_is_additive(B, be, O, dragon_1080p):
     """accum after passes (s0, s1) == single-pass(s0) + single-pass(s1) in float32 (path_tracing.glsl:255)."""
     W, H, c, tree, P = dragon_1080p
@@ -913,7 +999,7 @@ def test_full_size_frame_vs_reference_checksums(B, be, O, sc, tag, mode):
         be.set_mode(0)
 
 
-@pytest.mark.parametrize("wild", [False, True, "wild2"])
+@pytest.mark.parametrize("wild", [False, True, "wild2", "lattice"])
 def test_random_scenes_soak(wild):
     """tests/fuzz_parity.py: 60 random scenes of all four primitive types incl. degenerate ones (zero radii, zero-area
     and axis-aligned triangles, exact duplicates, cylinders), random cameras, user-sphere modes, Sun on/off, depths 1-8,
@@ -926,13 +1012,16 @@ def test_random_scenes_soak(wild):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # "wild2": the second class of hostile numbers (negative radii, the reference's magic numbers 1e19 / 1e-4 / 1e-8 / 1e-10, the
     # ends of the float range, denormals, odd cameras / user spheres / Sun altitudes; 8 000 cases of it found no difference)
-    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_parity.py")] + (["--wild2"] if wild == "wild2" else ["--wild"] if wild else []) + ["0", "60"]
+    # "lattice" (round 4): coplanar, overlapping axis-aligned triangles and discs, coincident spheres — boxes that are not
+    # conservative for their primitives in fp32, where the reference's winner hinges on its visiting order and the fast kernels'
+    # nearest-first walk has to notice (device_scene.h GD_NEAREST): without its certificate 133 of 1 500 such scenes differed
+    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_parity.py")] + (["--" + wild] if isinstance(wild, str) else ["--wild"] if wild else []) + ["0", "60"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60 scenes, 0 with differences" in r.stdout
 
 
-@pytest.mark.parametrize("flavour", ["", "--wild", "--wild2"])
+@pytest.mark.parametrize("flavour", ["", "--wild", "--wild2", "--lattice"])
 def test_random_scenes_through_the_renderer_api(flavour):
     """The same random cases through the C++ gpuart::Renderer — its own BVH build and upload (Renderer::SetPrimitives), camera
     basis, Sun direction and RandSeed draws instead of the oracle's — in both path-tracing pipelines: the whole product against
@@ -1024,7 +1113,16 @@ def test_headless_cli(B, O, tmp_path):
     for seed in O.randseeds(2):
         O.pt_pass(tree, c, W, H, P, seed, 2, acc)
     assert_bits(img.reshape(-1, 3), (acc[..., :3] / np.float32(4)).reshape(-1, 3), "CLI PFM vs oracle")
-    assert open(ppm, "rb").read().startswith(b"P6\n%d %d\n255\n" % (W, H))
+    # the 8-bit image: what the reference's default framebuffer shows of that frame (src/renderer.cpp:601-616 draws the
+    # normalised radiance into an 8-bit unsigned-normalised buffer: clamp to [0, 1], x 255, round to nearest), top row first
+    raw8 = open(ppm, "rb").read()
+    head8 = b"P6\n%d %d\n255\n" % (W, H)
+    assert raw8.startswith(head8) and len(raw8) == len(head8) + W * H * 3
+    got8 = np.frombuffer(raw8[len(head8):], np.uint8).reshape(H, W, 3)
+    scaled = (np.clip(img, 0.0, 1.0).astype(np.float32) * np.float32(255.0)).astype(np.float64)
+    exp8 = np.floor(scaled + 0.5).astype(np.uint8)[::-1]
+    np.testing.assert_array_equal(got8, exp8)
+    assert exp8.min() < 255 and exp8.max() == 255 and len(np.unique(exp8)) > 50  # a real image: clamped highlights and a range of greys
 
 
 def test_headless_cli_resume_continues_to_more_paths(tmp_path):
