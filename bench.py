@@ -50,19 +50,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-L1_PEAK_GACC = 1010.0           # the highest vector-L1 (TCP) cache-access rate tools/ubench reaches on the box with the product's own node fetch
-                                # (2 x dwordx4 + 2 x dwordx3 per lane, every lane its own record, records resident in the L1): 1.00-1.01e12/s, flat
-                                # from 4 to 8 waves per SIMD; 8.65-8.75e11 when 5-20 % of the accesses miss to L2 (profiles/r02/l1_access_calibration.txt).
-                                # One access per cycle and CU would be 614.4.
-STEP_PEAK_GVISITS = 227.0       # 64 lanes x 3.55e9 wave-steps/s: the rate at which tools/ubench (k_step) performs the product's traversal step — fetch one
-                                # 64-byte record per lane (every lane its own, L1-resident) + the two aabb_entry tests on it — at k_trace's 6 waves per SIMD
-                                # (8 waves: 3.73e9; fetch alone 4.05e9, tests alone 4.87e9: the hardware overlaps them to 1.14 x the slower one)
-VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling")
-VALU_MEASURED_GINSTR = 1058.0   # the highest issue rate tools/ubench reaches on the box: independent 4-byte v_add_f32, 128 between two branches, 8 waves per
-                                # SIMD = 2.32 cycles (6 waves: 2.44; 8-byte v_fma_f32: 2.54-2.72; profiles/r02/ubench.txt)
-VALU_SAME_MIX_GINSTR = 846.0    # the product's own box test on registers (87 VALU + 17 SALU per test: selects, dependent chains) at k_trace's 6 waves per SIMD:
-                                # 2.90 cycles per VALU instruction
+from gpuart_amd import bench_line as BL  # the roofline block's definitions and peaks (pure functions: tests/test_bench_line.py drives them)
 
 # The reference's own GLSL on Mesa llvmpipe, measured in the BUILD CONTAINER (8 vCPU; tests/golden/time_llvmpipe.py, output in
 # profiles/r02/llvmpipe_reference_glsl_container.txt). /root/reference cannot travel to the GPU box, so this is a recorded figure,
@@ -96,12 +84,12 @@ def parse_args():
                          "depth 4; cluster / tree: the reference's two primitive-list scenes (InitCluster / InitTree) on seeded stand-ins; "
                          "dragon871k: cfg3's workload on a mesh of the real Stanford dragon's size (the tree leaves the L2s)")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the K-pass timed sequence is run (median reported, min/max beside it)")
+    ap.add_argument("--no-verify-gather", action="store_true", help="N > 1: skip the untimed check of the gathered frame against rank 0's own whole-frame render")
     ap.add_argument("--gather-timeout", type=float, default=120.0,
                     help="N > 1: seconds a rank waits for the frame gather before it names the ranks that have not arrived and exits non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child runs (roofline counters become null)")
-    ap.add_argument("--verify-gather", action="store_true",
-                    help="rank 0 also renders the whole frame alone and checks the gathered frame against it bit for bit")
+    ap.add_argument("--verify-gather", action="store_true", help="(kept for old command lines: the check is always made for N > 1 now)")
     ap.add_argument("--render-only", action="store_true",
                     help="(internal) render warm-up + steps passes of the workload and exit: the program the rocprofv3 child runs profile")
     return ap.parse_args()
@@ -147,41 +135,47 @@ def run_passes(r, n):
         r.path_tracing_pass()
 
 
-def profile_children(args, K, Wm):
-    """rocprofv3 child runs of `bench.py --render-only` (the same W + K passes): SQ_INSTS_VALU etc. in one --pmc pass, FETCH_SIZE and
-    WRITE_SIZE in one pass each (the TCC slots do not hold both, MI355X_MICROARCH.md "rocprofv3 PMC slots"). Counters are summed over
-    every dispatch of the child and divided by its W + K passes. Returns (dict, note)."""
+PROFILE_REPEATS = 3  # the profiled children render the timed shape — K passes between two observations — this many times
+
+
+def profile_children(args, K):
+    """rocprofv3 child runs of `bench.py --render-only`: every child renders EXACTLY the timed shape (a sequence of K passes, PROFILE_REPEATS
+    times) and nothing else, so counters / (K x PROFILE_REPEATS) describe the schedule that ms_per_step times. One --pmc pass per
+    counter set (BL.PMC_SETS, filtered by what `--list-avail` offers: FETCH_SIZE and WRITE_SIZE do not share TCC slots, MI355X_MICROARCH.md
+    "rocprofv3 PMC slots") + one un-instrumented --kernel-trace pass for per-kernel durations in the real, overlapping schedule.
+    Returns (prof, trace, passes, note)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    child = [sys.executable, os.path.abspath(__file__), "--render-only", "--steps", str(K), "--warmup", str(Wm), "--workload", args.workload,
+        return None, None, 0, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--render-only", "--steps", str(K), "--repeats", str(PROFILE_REPEATS), "--workload", args.workload,
              "--frame", args.frame]
-    out = {}
     env = dict(os.environ, TMPDIR="/tmp")
-    for tag, counters in (("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES"]),
-                          ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]),
-                          ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"]),
-                          ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+    try:
+        avail = subprocess.run([exe, "--list-avail"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=120).stdout
+    except Exception:  # noqa: BLE001
+        avail = ""
+    prof, trace = {}, None
+    for tag, counters in BL.PMC_SETS + (("trace", None),):
+        if counters is not None:
+            counters = BL.pick_available(counters, avail)
+            if not counters:
+                continue
         d = tempfile.mkdtemp(prefix="gpuart_pmc_", dir="/tmp")
         try:
-            p = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc"] + counters + ["-d", d, "-o", "x", "--"] + child,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            cmd = [exe, "--kernel-trace", "--output-format", "csv"] + (["--pmc"] + counters if counters else []) + ["-d", d, "-o", "x", "--"] + child
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             if p.returncode != 0:
-                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(counters), p.returncode, (p.stderr or p.stdout)[-300:])
-            tot, per_kernel = {}, {}
-            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(path)):
-                    v = float(row["Counter_Value"])
-                    tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + v
-                    if row["Counter_Name"] == "SQ_INSTS_VALU":
-                        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-                        per_kernel[k] = per_kernel.get(k, 0.0) + v
-            out[tag] = (tot, per_kernel)
+                return None, None, 0, "rocprofv3 %s failed (rc %d): %s" % (tag, p.returncode, (p.stderr or p.stdout)[-300:])
+            if counters:
+                prof[tag] = BL.read_counters(d)
+            else:
+                trace = BL.read_kernel_trace(d)
         except Exception as e:  # noqa: BLE001
-            return None, "rocprofv3 child run failed: %r" % (e,)
+            return None, None, 0, "rocprofv3 child run failed: %r" % (e,)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return out, "rocprofv3 --pmc child runs of this invocation (`%s`), sums over all dispatches / %d passes" % (" ".join(child[1:]), K + Wm)
+    return prof, trace, K * PROFILE_REPEATS, ("rocprofv3 child runs of this invocation (`%s`): %d sequences of %d passes each, the timed shape; sums over all "
+                                               "dispatches / %d passes" % (" ".join(child[1:]), PROFILE_REPEATS, K, K * PROFILE_REPEATS))
 
 
 def main():
@@ -200,12 +194,10 @@ def main():
 
     if args.render_only:  # the profiled child: same scene, same seeds, same pass sequence; nothing else
         r, _, _, _ = make_renderer(args, W, H, 0, tmpdir)
-        r.set_seed(5489)
-        run_passes(r, Wm)
-        r.finish()
-        r.set_seed(5489)
-        run_passes(r, K)
-        r.finish()
+        for _ in range(max(1, args.repeats)):
+            r.set_seed(5489)
+            run_passes(r, K)
+            r.finish()
         r.close()
         shutil.rmtree(tmpdir, ignore_errors=True)
         return
@@ -323,6 +315,9 @@ def main():
                     print("bench.py rank %d: the frame gather did not complete within %.0f s (%s); ranks that never reached gather #%s: %s"
                           % (rank, args.gather_timeout, e, tag, missing_ranks(tag)), file=sys.stderr, flush=True)
                     os._exit(3)
+                # any other failure: every rank says what ITS library call reported (the peers' calls fail with "rank k could not
+                # prepare its share": the cause is in rank k's own message), then the rank ends non-zero
+                print("bench.py rank %d: gpuart_hip_gather #%s failed: %s" % (rank, tag, e), file=sys.stderr, flush=True)
                 raise
             return
         if host_tile is None:
@@ -407,26 +402,48 @@ def main():
                  "rccl_ranks": None}
         if gather_note is None:
             multi["rccl_ranks"] = be.comm_info()[0]  # ncclCommCount of the library's communicator
+            # which RCCL served the library's gather, and every librccl this process has mapped (torch.distributed brings its own
+            # copy: two different files here would mean two RCCL instances sharing the GPU's queues)
+            try:
+                multi["rccl_library"] = B.comm_library()
+            except B.HipError as e:
+                multi["rccl_library"] = "unknown (%s)" % e
+            try:
+                multi["rccl_mapped"] = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})
+            except OSError:
+                multi["rccl_mapped"] = None
+        multi["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
 
-    if dist is not None and gather_note is None and not args.verify_gather:
+    verify = dist is not None and not args.no_verify_gather
+    if dist is not None and gather_note is None and not verify:
         be.comm_destroy()  # every rank, while all of them are still alive
     if rank != 0:
         if dist is not None:
-            if args.verify_gather:
+            if verify:
                 dist.barrier()  # rank 0 is still checking the gathered frame
+                if gather_note is None:
+                    be.comm_destroy()
             dist.destroy_process_group()
         return
 
-    if args.verify_gather and dist is not None:
+    gather_verified = None
+    if verify:
+        # Once, untimed: the frame the last timed repetition gathered on rank 0 against rank 0's own render of the WHOLE frame (same
+        # passes, same seeds): a gather that moved rows wrongly, or a rank that rendered something else, shows here instead of never.
         assert r.set_tile(0, 0, W, H)
         r.set_seed(5489)
         run_passes(r, K)
         whole = r.read_radiance(True)
         got = full.cpu().numpy()
-        same = (got[..., :3].view(np.uint32) == whole[..., :3].view(np.uint32)).all()
-        print("verify-gather: gathered %d interleaved row sets == single-rank frame: %s" % (world, bool(same)), file=sys.stderr)
-        assert same, "gathered frame differs from the single-rank frame"
+        diff = (got[..., :3].view(np.uint32) != whole[..., :3].view(np.uint32)).any(-1)
+        gather_verified = not bool(diff.any())
+        multi["gather_verified"] = gather_verified
+        multi["gather_verified_note"] = ("gathered frame == rank 0's own whole-frame render of the same passes, bit for bit" if gather_verified else
+                                         "%d pixels differ; first differing frame rows: %s" % (int(diff.sum()), np.nonzero(diff.any(1))[0][:8].tolist()))
+        print("verify-gather: gathered %d interleaved row sets == single-rank frame: %s" % (world, gather_verified), file=sys.stderr)
         dist.barrier()
+        if gather_note is None:
+            be.comm_destroy()
 
     # ---- one pass alone, observed after it (the reference's interactive loop, src/main.cpp:549-599): frame time, not throughput ----
     single_ms = None
@@ -439,103 +456,19 @@ def main():
             ts.append((time.perf_counter() - t1) * 1e3)
         single_ms = float(np.median(ts[2:]))
 
-    # ---- roofline: device-level fractions (VALU issue, vector-L1 accesses, node visits, HBM), counters from rocprofv3 child runs of this invocation ----
+    # ---- roofline (gpuart_amd/bench_line.py): counters from rocprofv3 child runs of this invocation that render the timed shape ----
     ms_step = elapsed / K * 1e3
-    avg_kernel_ms = kernel_ms / max(1, launches)
-    roof = {"bound": "l1_accesses", "achieved": None, "peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "frac": None,
-            "traffic": None,
-            "definition": "TCP_TOTAL_CACHE_ACCESSES_sum of every kernel of a pass / ms_per_step (device level: overlapping launches are not "
-                          "double counted), against the highest L1 access rate measured on the box: 1.01e12/s with the product's own node-fetch "
-                          "shape on L1-resident records, flat from 4 to 8 waves per SIMD; 8.7e11/s when 5-20 % of the accesses miss to L2 "
-                          "(tools/ubench; one access per cycle and CU would be 6.14e11 -> frac_of_one_access_per_clock). The BVH queries are bound by vector-memory requests: every extra 16-byte fetch per node "
-                          "visit costs +12 % whether it hits L1 or not - its full service time at that peak rate - while extra VALU work costs a "
-                          "third of its issue time (profiles/r02/vector_memory_bound.txt); the real mix (misses, stores, narrow requests) costs "
-                          "more per access than the calibrating pattern",
-            "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s",
-                           "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step against 1024 SIMDs x 2.4 GHz / 2 cycles per "
-                                         "wave64 VALU instruction (`peak`); `peak_measured` = the highest rate any tools/ubench loop reaches on the box "
-                                         "(2.32 cycles), `peak_same_instruction_mix` = the product's own box test running on registers at 6 waves per SIMD "
-                                         "(2.90 cycles per VALU instruction)"},
-            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G node visits/s (lane level)",
-                            "achieved": round(exe[1] / elapsed / 1e9, 2), "frac": round(exe[1] / elapsed / 1e9 / STEP_PEAK_GVISITS, 4),
-                            "definition": "node visits the fast mode executes (device counters, mode-4 replay of the same passes) / wall time, against "
-                                          "64 x the rate at which a register-resident micro-benchmark performs the same step on L1-resident records with "
-                                          "every lane on its own record (tools/ubench k_step, profiles/r02/ubench_step.txt). A second opinion beside `frac`: "
-                                          "the pass spends its time on traversal steps at close to the rate the chip can perform them; it is not below 1 by "
-                                          "much because lanes that share a record (the top of the tree, coherent camera rays) are cheaper than the "
-                                          "calibrating pattern, and it ignores leaf tests, shading and path state"},
-            "kernel": "k_trace (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
-            "kernel_avg_ms": round(avg_kernel_ms, 5), "kernel_launches": launches, "kernel_ms_summed_per_pass": round(kernel_ms / (K * len(reps)), 4),
-            "kernel_concurrency": round(kernel_ms / (elapsed_all * 1e3), 3),
-            "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "algorithmic_bytes_per_pass_reference": alg_bytes / K, "algorithmic_bytes_per_pass_executed": exe[7] / K,
-                    "algorithmic_rate_executed": round(exe[7] / elapsed / 1e9, 1),
-                    "algorithmic_rate_over_peak": round(exe[7] / elapsed / 1e9 / HBM_PEAK_GBS, 3),
-                    "note": "algorithmic bytes (SURVEY.md 8(d): 48 B per node tested + 32/48/64/80 B per primitive tested + 32 B per pixel "
-                            "and pass) / wall time. Above the HBM peak because the tree is cache-resident (L2 / Infinity Cache): not a "
-                            "fraction of the HBM roofline; `traffic_frac` is"}}
+    prof = trace = None
+    passes_profiled = 0
     if world == 1 and not args.no_profile:
-        prof, note = profile_children(args, K, Wm)
-        roof["source"] = note
-        if prof:
-            n = K + Wm
-            v = prof["valu"][0]
-            valu = v.get("SQ_INSTS_VALU", 0.0) / n
-            vi = roof["valu_issue"]
-            vi["instr_per_pass"] = valu
-            vi["achieved"] = round(valu / (ms_step * 1e-3) / 1e9, 2)
-            vi["frac"] = round(vi["achieved"] / VALU_PEAK_GINSTR, 4)
-            vi["peak_measured"] = VALU_MEASURED_GINSTR
-            vi["frac_of_measured_peak"] = round(vi["achieved"] / VALU_MEASURED_GINSTR, 4)
-            vi["peak_same_instruction_mix"] = VALU_SAME_MIX_GINSTR
-            vi["frac_of_same_mix_peak"] = round(vi["achieved"] / VALU_SAME_MIX_GINSTR, 4)
-            if v.get("SQ_ACTIVE_INST_VALU"):
-                vi["lane_util"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
-            pk = prof["valu"][1]
-            tot = sum(pk.values()) or 1.0
-            vi["kernel_share"] = round(sum(x for k, x in pk.items() if k.startswith("k_trace")) / tot, 4)
-            vi["salu_instr_per_pass"] = v.get("SQ_INSTS_SALU", 0.0) / n
-            vi["vmem_read_instr_per_pass"] = v.get("SQ_INSTS_VMEM_RD", 0.0) / n
-            tc = prof["tcp"][0]
-            acc = tc.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / n
-            roof["l1_cache_accesses_per_pass"] = acc
-            roof["l1_requests_before_coalescing_per_pass"] = tc.get("TCP_TOTAL_ACCESSES_sum", 0.0) / n
-            roof["l1_misses_to_l2_per_pass"] = tc.get("TCP_TCC_READ_REQ_sum", 0.0) / n
-            roof["achieved"] = round(acc / (ms_step * 1e-3) / 1e9, 2)
-            roof["frac"] = round(roof["achieved"] / L1_PEAK_GACC, 4)
-            roof["frac_of_one_access_per_clock"] = round(roof["achieved"] / 614.4, 4)
-            l2 = prof["tcc"][0]
-            if l2.get("TCC_REQ_sum"):
-                roof["l2"] = {"requests_per_pass": l2["TCC_REQ_sum"] / n, "hits_per_pass": l2.get("TCC_HIT_sum", 0.0) / n,
-                              "misses_per_pass": l2.get("TCC_MISS_sum", 0.0) / n,
-                              "hit_rate": round(l2.get("TCC_HIT_sum", 0.0) / max(1.0, l2.get("TCC_HIT_sum", 0.0) + l2.get("TCC_MISS_sum", 0.0)), 4),
-                              "note": "TCC_HIT / TCC_MISS / TCC_REQ summed over the L2 channels and all kernels of a pass; misses go on to the "
-                                      "Infinity Cache and HBM (`traffic`)"}
-            # HBM traffic: FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B; calibrated for wide streams — our 16-B gathers
-            # are uncalibrated, read it as an upper estimate), both counters in KB; counts Infinity-Cache hits too
-            fetch = prof["fetch"][0].get("FETCH_SIZE", 0.0) / n
-            write = prof["write"][0].get("WRITE_SIZE", 0.0) / n
-            traffic = (2.0 * fetch + write) * 1024.0
-            roof["traffic"] = traffic
-            roof["hbm"].update({"traffic_bytes_per_pass": traffic, "FETCH_SIZE_KB_per_pass": fetch, "WRITE_SIZE_KB_per_pass": write,
-                                "traffic_rate": round(traffic / (ms_step * 1e-3) / 1e9, 1),
-                                "traffic_frac": round(traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        prof, trace, passes_profiled, source = profile_children(args, K)
     else:
-        roof["source"] = "not collected (%s)" % ("--no-profile" if args.no_profile else "N > 1: one GPU's counters would not describe the job")
-    # The line's headline fraction is the VALU-issue one, priced against the guide's peak (the only one of the three views whose peak is
-    # not of our own measuring); the vector-L1 view moves into `l1_accesses`, the step view stays in `node_visits`. The traversal step is
-    # balanced on the L1 address stage and VALU issue, so no single fraction tells the whole story.
-    l1_keys = ("achieved", "peak", "unit", "frac", "definition", "l1_cache_accesses_per_pass", "l1_requests_before_coalescing_per_pass",
-               "l1_misses_to_l2_per_pass", "frac_of_one_access_per_clock")
-    roof["l1_accesses"] = {k: roof.pop(k) for k in l1_keys if k in roof}
-    vi = roof["valu_issue"]
-    roof.update({"bound": "valu_issue", "achieved": vi.get("achieved"), "peak": vi["peak"], "unit": vi["unit"], "frac": vi.get("frac"),
-                 "definition": vi["definition"] + ". Beside it: `l1_accesses` (vector-L1 cache accesses against the highest rate measured on the box) and "
-                               "`node_visits` (executed node visits against the micro-benchmarked rate of the same traversal step); `traffic` = HBM "
-                               "bytes per pass from the PMC counters. NOTE: `frac` is a share of ISSUE SLOTS, not of useful work — removing "
-                               "wasted instructions lowers it: round 3's thin-wave modes issue 5.7e8 instead of 6.4e8 VALU instructions per "
-                               "pass (same rays, same node visits) in 6 % less time, which moves `frac` from 0.56 to 0.53 while "
-                               "`node_visits.frac` rises from 0.87 to 0.89-0.90"})
+        source = "not collected (%s)" % ("--no-profile" if args.no_profile else "N > 1: one GPU's counters would not describe the job")
+    roof = BL.assemble_roofline(ms_step, passes_profiled, prof, trace,
+                                executed={"nodes": exe[1] / K, "algorithmic_bytes": exe[7] / K},
+                                reference={"nodes": nodes / K, "algorithmic_bytes": alg_bytes / K},
+                                kernel_events=(kernel_ms, launches, elapsed_all))
+    roof["source"] = source
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample, rank 0, N=1 only ----
     cpu_baseline = None
@@ -560,6 +493,11 @@ def main():
         "metric": "Mrays/s (BVH queries EXECUTED by the timed fast mode: camera + bounce + Sun-shadow rays, device-counted; the "
                   "reference-defined count is in mrays_reference_defined_per_s), path tracing, 1 path/pixel/pass",
         "value": round(exe[0] / elapsed / 1e6, 3),
+        "value_definition": BL.VALUE_DEFINITION,
+        "metric_version": BL.METRIC_VERSION,
+        "metric_version_note": "1 (rounds 1-2): rays as the reference defines them; 2 (round 3): rays the fast mode executes; 3 (round 4): the same "
+                               "count, walked nearest-child-first (fewer box tests per ray). `value` is not comparable across versions — "
+                               "`ms_per_step` is, and `mrays_reference_defined_per_s` keeps version 1's definition",
         "unit": "Mrays/s",
         "n_gpus": world,
         "steps": K,
@@ -605,11 +543,13 @@ def main():
             "where": "BUILD CONTAINER (8 vCPU Xeon), not this box: the reference's unmodified GLSL on Mesa llvmpipe, same scene / camera / "
                      "ray definition (tests/golden/time_llvmpipe.py; profiles/r02/llvmpipe_reference_glsl_container.txt, profiles/r03/llvmpipe_reference_glsl_container_871k.txt)"},
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     r.close()
     shutil.rmtree(tmpdir, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+    if gather_verified is False:
+        sys.exit("bench.py: the gathered frame differs from rank 0's own whole-frame render (multi_gpu.gather_verified_note)")
 
 
 class _P2P:

@@ -1,0 +1,213 @@
+"""The part of bench.py that turns measurements into the `roofline` block of its JSON line — pure functions of numbers, no GPU, no
+subprocess — so that tests/test_bench_line.py can drive it on stubbed counters: a definition that drifts (a numerator and a
+denominator describing different schedules, a fraction of the wrong peak) fails a test instead of reaching the driver.
+
+What binds the path: branchy scalar fp32 per ray on a cache-resident tree. The headline is therefore the share
+of the chip's fp32 LANE slots that do work — VALU issue-slot share x the fraction of lanes active in an issued instruction — and
+beside it everything needed to read it: the issue-slot share itself, the wave-state split of the dominant kernel (executing /
+s_waitcnt / waiting to issue), vector-L1 accesses, node visits, HBM traffic against the algorithmic bytes, and per-kernel rows."""
+import csv
+import glob
+import os
+import re
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0           # aggregate L2 bandwidth, same guide ("L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s)
+VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide, "Wave scheduling")
+VALU_MEASURED_GINSTR = 1058.0   # the highest issue rate tools/ubench reaches on the box: independent 4-byte v_add_f32, 128 between two branches, 8 waves per
+                                # SIMD = 2.32 cycles (6 waves: 2.44; 8-byte v_fma_f32: 2.54-2.72; profiles/r02/ubench.txt)
+VALU_SAME_MIX_GINSTR = 846.0    # the product's own box test on registers (87 VALU + 17 SALU per test: selects, dependent chains) at k_trace's 6 waves per SIMD
+L1_PEAK_GACC = 1010.0           # the highest vector-L1 (TCP) cache-access rate tools/ubench reaches on the box with the product's own node fetch
+                                # (profiles/r02/l1_access_calibration.txt); one access per cycle and CU would be 614.4
+STEP_PEAK_GVISITS = 227.0       # 64 lanes x 3.55e9 wave-steps/s: tools/ubench k_step, the product's traversal step on L1-resident records at 6 waves per SIMD
+
+VALUE_DEFINITION = ("rays EXECUTED by the timed fast mode (closest-hit + Sun-shadow BVH queries it really performs, device-counted in an untimed "
+                    "mode-4 replay of the same passes) / wall time of the K timed passes")
+METRIC_VERSION = 3  # 1: reference-defined rays (rounds 1-2); 2: executed rays (round 3); 3: executed rays, nearest-child-first walks (round 4:
+                    # same ray count as 2, fewer node visits per ray) — `ms_per_step` is the figure that compares across versions
+
+# One small set per rocprofv3 --pmc pass (a set that asks for more than the hardware collects at once aborts the profiler); TA_* and
+# TCP stall counters are left out: rocprofiler refuses them on gfx950 (profiles/r03/pmc_ta_tcp_sets_abort.txt).
+PMC_SETS = (
+    ("wave", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]),
+    ("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS"]),
+    ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]),
+    ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"]),
+    ("fetch", ["FETCH_SIZE"]),
+    ("write", ["WRITE_SIZE"]),
+)
+
+
+def pick_available(counters, avail_text):
+    """The counters of a set that `rocprofv3 --list-avail` offers on this box (whole-word match), in order."""
+    return [c for c in counters if re.search(r"\b%s\b" % re.escape(c), avail_text)] if avail_text else list(counters)
+
+
+def kernel_family(name):
+    """`void (anonymous namespace)::k_trace<false, 6>(gd::Scene, ...)` -> `k_trace`."""
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").strip()
+    n = n.split("(")[0].split("<")[0]
+    return n.split("::")[-1]
+
+
+def read_counters(directory):
+    """Sums of every counter over all dispatches of a rocprofv3 output directory: ({counter: total}, {family: {counter: total}})."""
+    tot, fam = {}, {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            v = float(row["Counter_Value"])
+            c = row["Counter_Name"]
+            tot[c] = tot.get(c, 0.0) + v
+            f = fam.setdefault(kernel_family(row["Kernel_Name"]), {})
+            f[c] = f.get(c, 0.0) + v
+    return tot, fam
+
+
+def read_kernel_trace(directory):
+    """{family: (launches, summed ms)} of a rocprofv3 --kernel-trace output directory."""
+    out = {}
+    for path in glob.glob(os.path.join(directory, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            f = kernel_family(row["Kernel_Name"])
+            n, ms = out.get(f, (0, 0.0))
+            out[f] = (n + 1, ms + (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+    return out
+
+
+def _r(x, n=4):
+    return None if x is None else round(x, n)
+
+
+def wave_states(c):
+    """Split of the summed wave time of a kernel (SQ_WAVE_CYCLES) into executing an instruction / sitting in s_waitcnt / ready but
+    waiting for an issue slot — the reading of profiles/r03/thin_wave_modes.txt 0: ACTIVE_INST_ANY, WAIT_ANY, WAIT_INST_ANY."""
+    w = c.get("SQ_WAVE_CYCLES")
+    if not w:
+        return None
+    return {"executing": _r(c.get("SQ_ACTIVE_INST_ANY", 0.0) / w), "s_waitcnt": _r(c.get("SQ_WAIT_ANY", 0.0) / w),
+            "issue_wait": _r(c.get("SQ_WAIT_INST_ANY", 0.0) / w), "wave_cycles_per_pass": None}
+
+
+def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, reference, kernel_events, dominant="k_trace"):
+    """The `roofline` object of the bench line.
+      ms_per_step      : wall time of one timed pass (median repetition), ms
+      passes_profiled  : passes every profiled child rendered (the counters' denominator: the child renders the TIMED shape —
+                         K passes, repeated — and nothing else)
+      prof             : {set tag: (totals, per family)} from read_counters, or None
+      trace            : {family: (launches, summed ms)} of an un-instrumented --kernel-trace child, or None
+      executed / reference : dicts with nodes, algorithmic_bytes per pass (device counters of the fast mode / of the reference's work)
+      kernel_events    : (summed ms, launches, timed seconds) of the dominant kernel's launches measured live with HIP events
+    Every fraction is achieved / peak of the SAME quantity over the SAME passes; None where a counter is missing."""
+    s = ms_per_step * 1e-3
+    n = float(max(1, passes_profiled))
+    ev_ms, ev_n, ev_span = kernel_events
+    roof = {"bound": "valu_lanes", "achieved": None, "peak": round(VALU_PEAK_GINSTR * 64 / 1e3, 2), "unit": "T fp32 lane-operations/s", "frac": None,
+            "traffic": None,
+            "definition": "useful share of the chip's fp32 lane slots: wave64 VALU instructions of every kernel of a pass / ms_per_step x the "
+                          "lanes active in them (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), against 1024 SIMDs x 2.4 GHz / 2 cycles per "
+                          "wave64 VALU instruction x 64 lanes. = valu_issue.frac x valu_issue.lane_util. The path is branchy scalar fp32 per ray "
+                          "on a cache-resident tree: neither HBM nor MFMA is its roof (hbm.* and the algorithmic bytes are kept beside it, "
+                          "SURVEY.md 8(d)); `kernels` and `%s_wave_states` say where the rest of the slots go" % dominant,
+            "kernel": dominant + " (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
+            "kernel_avg_ms": _r(ev_ms / max(1, ev_n), 5), "kernel_launches": ev_n,
+            "kernel_concurrency": _r(ev_ms / (ev_span * 1e3), 3) if ev_span else None,
+            "kernel_avg_ms_note": "HIP events around every launch of that kernel on the stream it is launched on, during the timed passes; launches of "
+                                  "up to 8 pass lanes overlap (`kernel_concurrency` = summed kernel time / wall time), so per-launch figures are diagnostics",
+            "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s", "achieved": None, "frac": None,
+                           "peak_measured": VALU_MEASURED_GINSTR, "peak_same_instruction_mix": VALU_SAME_MIX_GINSTR,
+                           "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step: a share of ISSUE SLOTS (wasted instructions raise it)"},
+            "l1_accesses": {"peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "achieved": None, "frac": None,
+                            "definition": "TCP_TOTAL_CACHE_ACCESSES_sum of every kernel of a pass / ms_per_step against the highest rate tools/ubench "
+                                          "reaches on the box with the product's node-fetch shape (one access per cycle and CU: 614.4)"},
+            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G node visits/s (lane level)",
+                            "achieved": _r(executed["nodes"] / s / 1e9, 2), "frac": _r(executed["nodes"] / s / 1e9 / STEP_PEAK_GVISITS),
+                            "definition": "box tests the fast mode executes (device counters; both children of every record it visits) / ms_per_step, "
+                                          "against 64 x the rate of tools/ubench's register-resident traversal step (own peak: a second opinion)"},
+            "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "algorithmic_bytes_per_pass_reference": reference["algorithmic_bytes"],
+                    "algorithmic_bytes_per_pass_executed": executed["algorithmic_bytes"],
+                    "algorithmic_rate_executed": _r(executed["algorithmic_bytes"] / s / 1e9, 1),
+                    "algorithmic_rate_over_peak": _r(executed["algorithmic_bytes"] / s / 1e9 / HBM_PEAK_GBS, 3),
+                    "algorithmic_rate_over_l2_peak": _r(executed["algorithmic_bytes"] / s / 1e9 / L2_PEAK_GBS, 3),
+                    "note": "algorithmic bytes (SURVEY.md 8(d): 48 B per box tested + 32/48/64/80 B per primitive tested + 32 B per pixel and "
+                            "pass) / ms_per_step. Above the HBM peak because the tree is served by L1 / L2 / Infinity Cache, not HBM: against the "
+                            "guide's aggregate L2 rate (34.5 TB/s) the same bytes are `algorithmic_rate_over_l2_peak`; what really crosses to "
+                            "memory is `traffic_*` (PMC)"},
+            "kernels": None}
+    if not prof:
+        return roof
+    valu_t, valu_f = prof.get("valu", ({}, {}))
+    wave_t, wave_f = prof.get("wave", ({}, {}))
+    tcp_t, tcp_f = prof.get("tcp", ({}, {}))
+    tcc_t, _ = prof.get("tcc", ({}, {}))
+    fetch_t, fetch_f = prof.get("fetch", ({}, {}))
+    write_t, write_f = prof.get("write", ({}, {}))
+    vi = roof["valu_issue"]
+    if valu_t.get("SQ_INSTS_VALU"):
+        instr = valu_t["SQ_INSTS_VALU"] / n
+        vi["instr_per_pass"] = instr
+        vi["achieved"] = _r(instr / s / 1e9, 2)
+        vi["frac"] = _r(instr / s / 1e9 / VALU_PEAK_GINSTR)
+        vi["frac_of_measured_peak"] = _r(instr / s / 1e9 / VALU_MEASURED_GINSTR)
+        vi["frac_of_same_mix_peak"] = _r(instr / s / 1e9 / VALU_SAME_MIX_GINSTR)
+        vi["salu_instr_per_pass"] = valu_t.get("SQ_INSTS_SALU", 0.0) / n
+        vi["vmem_read_instr_per_pass"] = valu_t.get("SQ_INSTS_VMEM_RD", 0.0) / n
+        if valu_t.get("SQ_ACTIVE_INST_VALU"):
+            lu = valu_t["SQ_THREAD_CYCLES_VALU"] / (64.0 * valu_t["SQ_ACTIVE_INST_VALU"])
+            vi["lane_util"] = _r(lu)
+            roof["achieved"] = _r(instr * 64 * lu / s / 1e12, 3)
+            roof["frac"] = _r(instr * lu / s / 1e9 / VALU_PEAK_GINSTR)
+    if tcp_t.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        acc = tcp_t["TCP_TOTAL_CACHE_ACCESSES_sum"] / n
+        l1 = roof["l1_accesses"]
+        l1.update({"l1_cache_accesses_per_pass": acc, "l1_requests_before_coalescing_per_pass": tcp_t.get("TCP_TOTAL_ACCESSES_sum", 0.0) / n,
+                   "l1_misses_to_l2_per_pass": tcp_t.get("TCP_TCC_READ_REQ_sum", 0.0) / n,
+                   "achieved": _r(acc / s / 1e9, 2), "frac": _r(acc / s / 1e9 / L1_PEAK_GACC), "frac_of_one_access_per_clock": _r(acc / s / 1e9 / 614.4)})
+    if tcc_t.get("TCC_REQ_sum"):
+        hit, miss = tcc_t.get("TCC_HIT_sum", 0.0), tcc_t.get("TCC_MISS_sum", 0.0)
+        roof["l2"] = {"requests_per_pass": tcc_t["TCC_REQ_sum"] / n, "hits_per_pass": hit / n, "misses_per_pass": miss / n,
+                      "hit_rate": _r(hit / max(1.0, hit + miss)),
+                      "note": "TCC_HIT / TCC_MISS / TCC_REQ summed over the L2 channels and all kernels of a pass; misses go on to the Infinity Cache and HBM"}
+    if "FETCH_SIZE" in fetch_t or "WRITE_SIZE" in write_t:
+        # FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B; calibrated for wide streams — 16-B gathers are uncalibrated: an upper
+        # estimate), both counters in KB; Infinity-Cache hits are counted too (the guide's HBM / rocprofv3 section)
+        fetch, write = fetch_t.get("FETCH_SIZE", 0.0) / n, write_t.get("WRITE_SIZE", 0.0) / n
+        traffic = (2.0 * fetch + write) * 1024.0
+        roof["traffic"] = traffic
+        roof["hbm"].update({"traffic_bytes_per_pass": traffic, "FETCH_SIZE_KB_per_pass": fetch, "WRITE_SIZE_KB_per_pass": write,
+                            "traffic_rate": _r(traffic / s / 1e9, 1), "traffic_frac": _r(traffic / s / 1e9 / HBM_PEAK_GBS),
+                            "traffic_over_algorithmic": _r(traffic / max(1.0, executed["algorithmic_bytes"]), 3)})
+    # per kernel family: where the time, the instructions and the memory traffic of a pass go
+    fams = sorted(set(valu_f) | set(wave_f) | set(fetch_f) | set(write_f) | set(trace or {}))
+    rows = []
+    total_ms = sum(ms for _, ms in (trace or {}).values()) or None
+    for f in fams:
+        v, w = valu_f.get(f, {}), wave_f.get(f, {})
+        row = {"kernel": f}
+        if trace and f in trace:
+            row["launches_per_pass"] = _r(trace[f][0] / n, 3)
+            row["ms_summed_per_pass"] = _r(trace[f][1] / n)
+            row["share_of_summed_kernel_time"] = _r(trace[f][1] / total_ms)
+        if v.get("SQ_INSTS_VALU") is not None:
+            row["valu_instr_per_pass"] = v.get("SQ_INSTS_VALU", 0.0) / n
+            row["salu_instr_per_pass"] = v.get("SQ_INSTS_SALU", 0.0) / n
+            if v.get("SQ_ACTIVE_INST_VALU"):
+                row["lane_util"] = _r(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]))
+        if f in fetch_f or f in write_f:
+            row["hbm_fetch_bytes_per_pass"] = 2.0 * fetch_f.get(f, {}).get("FETCH_SIZE", 0.0) / n * 1024.0
+            row["hbm_write_bytes_per_pass"] = write_f.get(f, {}).get("WRITE_SIZE", 0.0) / n * 1024.0
+        if f in tcp_f:
+            row["l1_cache_accesses_per_pass"] = tcp_f[f].get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / n
+        ws = wave_states(w)
+        if ws:
+            ws["wave_cycles_per_pass"] = w["SQ_WAVE_CYCLES"] / n
+            row["wave_states"] = ws
+        rows.append(row)
+    rows.sort(key=lambda r: -(r.get("ms_summed_per_pass") or 0.0))
+    roof["kernels"] = rows
+    dom = next((r for r in rows if r["kernel"] == dominant), None)
+    roof[dominant + "_wave_states"] = dom.get("wave_states") if dom else None
+    roof["kernels_note"] = ("per kernel family and pass: ms_summed = kernel durations of an un-instrumented --kernel-trace child (launches overlap: the "
+                            "sum exceeds ms_per_step), instruction counts / lane_util / wave states / memory bytes from the --pmc children (which "
+                            "serialise the kernels: counts are schedule-independent, the wave-state split is that of a launch running alone)")
+    return roof

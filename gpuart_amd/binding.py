@@ -194,6 +194,16 @@ def scatter_rows_host(g, tile_rgba, full_rgba):
     return full_rgba
 
 
+def comm_library():
+    """Path of the RCCL library libgpuart_hip resolved its entry points from (dladdr of ncclCommInitRank)."""
+    L = hip_lib()
+    buf = C.create_string_buffer(4096)
+    rc = L.gpuart_hip_comm_library(buf, C.c_size_t(len(buf)))
+    if rc != 0:
+        raise HipError("gpuart_hip error %d: %s" % (rc, L.gpuart_hip_last_error().decode()))
+    return buf.value.decode()
+
+
 def comm_unique_id():
     """gpuart_hip_comm_unique_id (ncclGetUniqueId): 128 bytes for rank 0 to hand to the other ranks."""
     buf = (C.c_ubyte * 128)()
@@ -326,6 +336,10 @@ class Backend:
     def wait(self, timeout_ms):
         """finish() with a bound: HipError with code ERR_TIMEOUT if the context's work is not complete after timeout_ms."""
         self._chk(self.L.gpuart_hip_wait(self.ctx, C.c_uint32(int(timeout_ms))))
+
+    def test_stall(self, ms):
+        """Keeps the context's primary stream busy for `ms` milliseconds (what a missing peer looks like to the bounded waits)."""
+        self._chk(self.L.gpuart_hip_test_stall(self.ctx, C.c_uint32(int(ms))))
 
     MODE_WAVEFRONT, MODE_REFERENCE_WORK, MODE_MEGAKERNEL = 0, 1, 2
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <cmath>
@@ -136,6 +137,10 @@ struct gpuart_hip_ctx {
     float4 *d_send = nullptr, *d_stage = nullptr;
     size_t send_pixels = 0, stage_pixels = 0;
     void *d_hello = nullptr;          ///< [1 + nranks] GatherHello: own share + status, then everybody's (ncclAllGather)
+    void *h_hello = nullptr;          ///< pinned host copy of that table: the exchange's device-to-host copy must be truly asynchronous
+                                      ///< (the bounded wait comes AFTER it is queued) and its target must outlive a timed-out call
+    uint64_t comm_group = 0;          ///< which communicator this context is a rank of: contexts joined by one _comm_init_all (or one
+                                      ///< unique id) share it; gpuart_hip_gather_all refuses ranks of different communicators
     uint32_t gather_timeout_ms = 60000;  ///< GPUART_HIP_GATHER_TIMEOUT_MS: bound on the host-side wait for the peers (0: none)
 };
 
@@ -422,6 +427,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor,
                     c->d_send, c->d_stage, c->d_hello};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_hello) (void)hipHostFree(c->h_hello);  // (after drain: no copy into it is queued any more)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -905,8 +911,15 @@ int gpuart_hip_comm_unique_id(void *id128) {
 
 static int comm_drop(gpuart_hip_ctx *c) {
     if (c->comm && c->comm_owned) (void)rccl()->CommDestroy(c->comm);
-    c->comm = nullptr; c->comm_owned = false; c->comm_nranks = 0; c->comm_rank = 0;
+    c->comm = nullptr; c->comm_owned = false; c->comm_nranks = 0; c->comm_rank = 0; c->comm_group = 0;
     return 0;
+}
+
+/// Identity of a communicator for gpuart_hip_gather_all: process-unique serials for _comm_init_all / _comm_attach, a hash of the
+/// unique id for _comm_init (the same on every rank that was given that id).
+static uint64_t next_comm_group() {
+    static std::atomic<uint64_t> serial{1};
+    return serial.fetch_add(1);
 }
 
 int gpuart_hip_comm_init(gpuart_hip_ctx *c, int nranks, int rank, const void *id128) {
@@ -919,6 +932,9 @@ int gpuart_hip_comm_init(gpuart_hip_ctx *c, int nranks, int rank, const void *id
     memcpy(&id, id128, sizeof id);
     NCCL_TRY(rccl()->CommInitRank(&c->comm, nranks, id, rank));
     c->comm_owned = true; c->comm_nranks = nranks; c->comm_rank = rank;
+    uint64_t h = 1469598103934665603ull;  // FNV-1a of the 128-byte id; bit 63 set: never a serial
+    for (size_t k = 0; k < sizeof id; k++) h = (h ^ ((const unsigned char *)&id)[k]) * 1099511628211ull;
+    c->comm_group = h | (1ull << 63);
     return 0;
 }
 
@@ -928,6 +944,7 @@ int gpuart_hip_comm_attach(gpuart_hip_ctx *c, void *nccl_comm, int nranks, int r
     if (r) return r;
     comm_drop(c);
     c->comm = (ncclComm_t)nccl_comm; c->comm_owned = false; c->comm_nranks = nranks; c->comm_rank = rank;
+    c->comm_group = 0;  // the caller's communicator: which handles belong together is the caller's to know
     return 0;
 }
 
@@ -943,10 +960,18 @@ int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n) {
         for (int m = 0; m < k; m++)
             if (devs[m] == devs[k]) return fail(GPUART_HIP_ERR_ARG, "two contexts of one communicator on the same device");
     }
-    NCCL_TRY(rccl()->CommInitAll(comms.data(), n, devs.data()));
+    // a context leaves its previous communicator first (with its work drained: nothing of that communicator is in flight)
     for (int k = 0; k < n; k++) {
+        if (!ctxs[k]->comm) continue;
+        HIP_TRY(hipSetDevice(ctxs[k]->device));
+        if ((r = drain(ctxs[k]))) return r;
         comm_drop(ctxs[k]);
+    }
+    NCCL_TRY(rccl()->CommInitAll(comms.data(), n, devs.data()));
+    const uint64_t group = next_comm_group();
+    for (int k = 0; k < n; k++) {
         ctxs[k]->comm = comms[k]; ctxs[k]->comm_owned = true; ctxs[k]->comm_nranks = n; ctxs[k]->comm_rank = k;
+        ctxs[k]->comm_group = group;
     }
     return 0;
 }
@@ -997,6 +1022,8 @@ int gather_prepare(gpuart_hip_ctx *c, int which, float divide_by, int root, Gath
 /// stay uninitialised in the root's frame, rows rendered twice would depend on the order of the transfers.
 int check_shares(const std::vector<GatherHello> &all, int which, int root) {
     const gpuart_tile_geom &g0 = all[0].g;
+    // (before anything is sized by it: a share table is other ranks' — or a caller's — data)
+    if (!geom_ok(g0) || g0.H > 65536 || g0.W > 65536) return fail(GPUART_HIP_ERR_ARG, "gather: inconsistent shares (frame of rank 0)");
     std::vector<uint8_t> cover(g0.H, 0);
     for (size_t k = 0; k < all.size(); k++) {
         const gpuart_tile_geom &g = all[k].g;
@@ -1067,14 +1094,29 @@ int wait_stream(gpuart_hip_ctx *c, uint32_t timeout_ms, const char *what) {
 
 int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *status, int n, int which, int root) {
     if (!shares || n < 1 || n > 1024) return fail(GPUART_HIP_ERR_ARG, "bad argument");
-    std::vector<GatherHello> all((size_t)n);
-    for (int k = 0; k < n; k++) {
-        memset(&all[(size_t)k], 0, sizeof(GatherHello));
-        all[(size_t)k].g = shares[k];
-        all[(size_t)k].status = status ? status[k] : 0u;
-        all[(size_t)k].which = (uint32_t)which; all[(size_t)k].root = (uint32_t)root;
+    try {
+        std::vector<GatherHello> all((size_t)n);
+        for (int k = 0; k < n; k++) {
+            memset(&all[(size_t)k], 0, sizeof(GatherHello));
+            all[(size_t)k].g = shares[k];
+            all[(size_t)k].status = status ? status[k] : 0u;
+            all[(size_t)k].which = (uint32_t)which; all[(size_t)k].root = (uint32_t)root;
+        }
+        return check_shares(all, which, root);
+    } catch (const std::exception &e) {  // no exception crosses the C ABI
+        return fail(GPUART_HIP_ERR_ARG, std::string("share table: ") + e.what());
     }
-    return check_shares(all, which, root);
+}
+
+int gpuart_hip_comm_library(char *path, size_t size) {
+    if (!path || size < 2) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    int r = need_rccl();
+    if (r) return r;
+    Dl_info di;
+    memset(&di, 0, sizeof di);
+    if (!dladdr((void *)rccl()->CommInitRank, &di) || !di.dli_fname) return fail(GPUART_HIP_ERR_DEVICE, "dladdr(ncclCommInitRank) failed");
+    snprintf(path, size, "%s", di.dli_fname);
+    return 0;
 }
 
 int gpuart_hip_comm_info(gpuart_hip_ctx *c, int *nranks, int *rank) {
@@ -1115,15 +1157,20 @@ int gpuart_hip_gather(gpuart_hip_ctx *c, int which, float divide_by, int root, v
     own.status = mine ? 1u : 0u;
     if (!c->d_hello && hipMalloc(&c->d_hello, (size_t)(1 + 1024) * sizeof(GatherHello)) != hipSuccess)
         return fail(GPUART_HIP_ERR_DEVICE, "gather: no device memory for the share table (the other ranks are left waiting: nothing can be told to them)");
-    // 2. everybody's share and status, through the communicator itself (12 words per rank)
-    std::vector<GatherHello> all((size_t)n);
-    GatherHello *d = (GatherHello *)c->d_hello;
-    HIP_TRY(hipMemcpyAsync(d, &own, sizeof own, hipMemcpyHostToDevice, c->stream));
+    if (!c->h_hello && hipHostMalloc(&c->h_hello, (size_t)(1 + 1024) * sizeof(GatherHello), hipHostMallocDefault) != hipSuccess)
+        return fail(GPUART_HIP_ERR_DEVICE, "gather: no pinned host memory for the share table (the other ranks are left waiting: nothing can be told to them)");
+    // 2. everybody's share and status, through the communicator itself (12 words per rank). Both host ends of the two copies are
+    //    the context's pinned table: the copies are queued, not performed, by these calls — the wait below is the only place this
+    //    rank can block, and it is bounded —, and a call that gives up leaves no queued copy pointing at its own stack or heap.
+    GatherHello *d = (GatherHello *)c->d_hello, *hh = (GatherHello *)c->h_hello;
+    hh[0] = own;
+    HIP_TRY(hipMemcpyAsync(d, hh, sizeof own, hipMemcpyHostToDevice, c->stream));
     NCCL_TRY(rccl()->AllGather(d, d + 1, sizeof own / 4, ncclUint32, c->comm, c->stream));
-    HIP_TRY(hipMemcpyAsync(all.data(), d + 1, (size_t)n * sizeof own, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hh + 1, d + 1, (size_t)n * sizeof own, hipMemcpyDeviceToHost, c->stream));
     int r = wait_stream(c, c->gather_timeout_ms, "gather: exchange of the shares");
     if (r) return r;
     if (mine) return fail(mine, my_error);
+    std::vector<GatherHello> all(hh + 1, hh + 1 + n);
     // 3. the same table on every rank: the same verdict on every rank
     if ((r = check_shares(all, which, root))) return r;
     // 4. the transfers
@@ -1142,7 +1189,7 @@ int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float d
     std::vector<GatherHello> all((size_t)n);
     // one thread drives every rank: all local preparation first, transfers only when every rank is ready
     for (int k = 0; k < n; k++) {
-        if (!ctxs[k] || !ctxs[k]->comm || ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k)
+        if (!ctxs[k] || !ctxs[k]->comm || ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k || ctxs[k]->comm_group != ctxs[0]->comm_group)
             return fail(GPUART_HIP_ERR_NO_COMM, "contexts are not the ranks 0..n-1 of one communicator (gpuart_hip_comm_init_all)");
     }
     for (int k = 0; k < n; k++) {
@@ -1308,6 +1355,23 @@ int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
     float *outs[] = {rstart, rdir};
     Frame f = c->frame;
     return run_hook(c, n, nullptr, 0, outs, 2, [&](auto &, auto &o) { k_test_cam_rays<<<GRID1(n)>>>(f, o[0], o[1]); });
+}
+
+namespace {
+/// One wave that keeps the stream busy for `ticks` of the 100 MHz wall clock (gpuart_hip_test_stall): it ends by itself.
+__global__ void k_test_stall(unsigned long long ticks, unsigned long long *sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long n = 0;
+    while (wall_clock64() - t0 < ticks) n++;
+    if (sink && threadIdx.x == 0) *sink = n;
+}
+}  // namespace
+int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
+    if (!c || ms > 5000) return fail(GPUART_HIP_ERR_ARG, "bad argument (at most 5000 ms)");
+    HIP_TRY(hipSetDevice(c->device));
+    k_test_stall<<<1, 64, 0, c->stream>>>((unsigned long long)ms * 100000ull, nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 #ifdef GD_RUN_TIMELINE

@@ -157,6 +157,9 @@ int gpuart_hip_comm_init(gpuart_hip_ctx *ctx, int nranks, int rank, const void *
 int gpuart_hip_comm_attach(gpuart_hip_ctx *ctx, void *nccl_comm, int nranks, int rank);
 int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n);
 int gpuart_hip_comm_destroy(gpuart_hip_ctx *ctx);
+/* Which RCCL the library resolved its entry points from (dladdr of ncclCommInitRank): a process that also holds another
+ * framework's RCCL — torch.distributed's, say — can record that both are the same file. Loads RCCL if nothing has yet. */
+int gpuart_hip_comm_library(char *path, size_t size);
 /* What the communicator itself says (ncclCommCount, ncclCommUserRank); GPUART_HIP_ERR_ARG without one. */
 int gpuart_hip_comm_info(gpuart_hip_ctx *ctx, int *nranks, int *rank);
 
@@ -233,6 +236,10 @@ int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_op
  * `status[k]` (0: ready) as rank k announced them. 0 if the gather would go ahead — full-width rows, every frame row covered
  * exactly once, every rank ready — else the error code it would return on every rank (gpuart_hip_last_error says why). */
 int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *status, int n, int which, int root);
+
+/* Keeps the context's primary stream busy for `ms` milliseconds (one idle-spinning wave that ends by itself; at most 5000):
+ * what a peer that has not arrived looks like to the bounded waits of gpuart_hip_gather / gpuart_hip_wait, on one GPU. */
+int gpuart_hip_test_stall(gpuart_hip_ctx *ctx, uint32_t ms);
 
 /* ---- device-function test hooks (parity tests call the device code through these) ----------
  * Arrays are n x 4 float32 in host memory. Each mirrors one reference GLSL function. */

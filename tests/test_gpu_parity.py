@@ -1200,6 +1200,50 @@ def test_rccl_gather_with_one_rank(B, be, O):
         be.resize(W, H)
 
 
+def test_gather_gives_up_within_its_bound_and_the_context_survives(B, O, monkeypatch):
+    """The exchange of the shares cannot complete (one GPU: the stream is held by gpuart_hip_test_stall, as a peer that never
+    arrives would hold it): gpuart_hip_gather must come back with GPUART_HIP_ERR_TIMEOUT within GPUART_HIP_GATHER_TIMEOUT_MS — it
+    used to copy the all-gathered table into a pageable vector on its own stack BEFORE the bounded wait, i.e. either block in that
+    copy for ever or, giving up, leave a queued copy pointing at freed memory. The table now lives in pinned memory owned by the
+    context: when the stall ends the queued exchange completes harmlessly, and the next gather works."""
+    import time
+    import torch
+    monkeypatch.setenv("GPUART_HIP_GATHER_TIMEOUT_MS", "150")
+    W, H = 72, 40
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    c = O.camera(cam["pos"], cam["dir"], cam["up"], cam["fov_y"], cam["screen_dist"], W, H)
+    tree, _ = O.build_bvh(scene("box"))
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(c[12]), c[0:3], 5, 0.01)
+    b2 = B.Backend(0)
+    try:
+        b2.resize(W, H); b2.upload_bvh(tree); b2.set_camera(c)
+        b2.comm_init(1, 0, B.comm_unique_id())
+        b2.pt_reset()
+        b2.pt_pass(to_params(B, P), O.randseeds(1)[0], 1)
+        tile = b2.read(1)
+        full = torch.full((H, W, 4), -7.0, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        b2.test_stall(1500)
+        t0 = time.perf_counter()
+        with pytest.raises(B.HipError) as e:
+            b2.gather(1, 1.0, 0, full.data_ptr())
+        dt = time.perf_counter() - t0
+        assert e.value.code == -4 and "not complete after 150 ms" in str(e.value), str(e.value)  # GPUART_HIP_ERR_TIMEOUT
+        assert 0.14 < dt < 1.0, dt
+        with pytest.raises(B.HipError) as e:
+            b2.wait(100)  # still stalled: the bounded wait of gpuart_hip_wait says so too
+        assert e.value.code == -4
+        b2.wait(10000)    # the stall ends by itself; what the abandoned call had queued completes into the context's own table
+        assert (full.cpu().numpy() == -7.0).all()  # nothing was transferred by the call that gave up
+        b2.gather(1, 1.0, 0, full.data_ptr())
+        b2.wait(10000)
+        assert_bits(full.cpu().numpy().reshape(-1, 4), tile.reshape(-1, 4), "gather after a timed-out one")
+    finally:
+        b2.comm_destroy()
+        b2.close()
+
+
 def test_headless_cli_gather_path(tmp_path):
     """gpuart_cli's multi-GPU read-out (Renderer::GatherRadiance -> gpuart_hip_gather_all over ncclCommInitAll) with the one
     rank a single-GPU box allows == the plain read-back."""

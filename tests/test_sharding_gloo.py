@@ -71,6 +71,11 @@ def test_share_table_validation_of_the_gather():
     rc, why = verdict([good[0], good[1], narrow]); assert rc != 0 and "full-width" in why
     rc, why = verdict(good, status=[0, 1, 0]); assert rc != 0 and "rank 1 could not prepare" in why
     assert verdict(good, status=[0, 0, 0])[0] == 0
+    # a bogus frame in rank 0's entry (caller / peer data sizes the coverage map): an argument error, not a 4 GB allocation or an
+    # exception across the C ABI
+    for bad_h in (0xffffffff, 70000, 0):
+        bogus = B.share_of_rank(W, H, 0, 1); bogus.H = bad_h
+        rc, why = verdict([bogus]); assert rc == -1 and "inconsistent shares" in why, (bad_h, rc, why)
 
 
 def _free_port():
