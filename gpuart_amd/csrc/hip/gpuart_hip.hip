@@ -227,7 +227,8 @@ int realloc_tile(gpuart_hip_ctx *c) {
 int ensure_segment_counters(gpuart_hip_ctx *c, PassLane &l, uint32_t nseg) {
     if (l.pb.counters && l.counter_segments >= nseg) return 0;
     if (l.pb.counters) { int r = drain(c); if (r) return r; (void)hipFree(l.pb.counters); l.pb.counters = nullptr; }
-    HIP_TRY(hipMalloc(&l.pb.counters, 4 * ((size_t)nseg + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&l.pb.counters, 20 * ((size_t)nseg + 1) * sizeof(uint32_t)));  // 4 words per segment + 16 per-XCD cursors (experiment)
+    l.pb.xcd_cursors = l.pb.counters + 4 * ((size_t)nseg + 1);
     l.counter_segments = nseg;
     return 0;
 }
@@ -382,6 +383,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.refill_lanes = env_u32("GPUART_HIP_REFILL_LANES", 16, 1, 64);
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
     c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
+    c->tune.xcd_queues = env_u32("GPUART_HIP_XCD_QUEUES", 0, 0, 1);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->plan.lanes_total = (uint32_t)c->lanes.size();
@@ -683,6 +685,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     for (int j = 0; j < npaths; j++) {
         j_cur = j;
         HIP_TRY(hipMemsetAsync(b.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
+        if (c->tune.xcd_queues) HIP_TRY(hipMemsetAsync(b.xcd_cursors, 0, 16 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
         k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seeds, j, npaths, b, l.passcolor);
         if (nseg && (r = trace(0, -1))) return r;
         for (uint32_t seg = 0; seg < nseg; seg++) {

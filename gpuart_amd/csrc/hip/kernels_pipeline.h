@@ -21,6 +21,9 @@ struct TraceTuning {
     uint32_t refill_lanes;  ///< a wave goes back for new rays once this many lanes are idle
     uint32_t leaf_lanes;    ///< primitive tests are issued once this many lanes wait at a leaf ...
     uint32_t leaf_share;    ///< ... or 1/leaf_share of the lanes that still hold a ray
+    uint32_t xcd_queues;    ///< experiment (GPUART_HIP_XCD_QUEUES, default 0): the waves of XCD x (workgroup index mod 8) serve the x-th
+                            ///< eighth of the ray queue — contiguous slots, one region of the image — from a cursor of their own, so
+                            ///< that an XCD's L2 sees one eighth of the rays' working set; no stealing between the eighths
 };
 
 // =================================================================================================
@@ -46,6 +49,7 @@ struct PathBuffers {
     uint32_t *shadow_queue;  ///< slots with a pending Sun shadow query
     uint32_t *counters;      ///< per segment s: [4s] closest-hit rays, [4s+1] k_trace's fetch cursor (for the launch whose
                              ///< closest part is s), [4s+2] shadow rays, [4s+3] fetch cursor of a shadow-only launch
+    uint32_t *xcd_cursors;   ///< [16s + x] / [16s + 8 + x]: the same two cursors per XCD x (TraceTuning::xcd_queues)
     uint32_t n_slots;        ///< path slots per pass (pixels of the tile, 8x8-tile padded)
     uint32_t batch;          ///< passes processed together: slot s belongs to pass s / n_slots, pixel slot s % n_slots
     uint32_t tile_pixels;    ///< stride between the passes' colour planes in `passcolor`
@@ -256,8 +260,17 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
 
     // The first chunk of every wave is static (chunk index = workgroup index); later chunks come from the
     // shared cursor, which therefore starts behind the static ones. No atomic at all for small queues.
-    const uint32_t static_end = n_waves * tune.chunk;
+    uint32_t static_end = n_waves * tune.chunk;
     uint32_t chunk_next = min(wave_id * tune.chunk, n), chunk_end = min((wave_id + 1) * tune.chunk, n);  // wave-uniform
+    uint32_t q_end = n;  // end of the part of the queue this wave serves
+    if (tune.xcd_queues) {  // (experiment) this wave's XCD serves its own eighth of the queue
+        const uint32_t xcd = wave_id & 7u, wx = wave_id >> 3, nwx = (n_waves + 7u - xcd) >> 3;
+        const uint32_t lo = (uint32_t)((unsigned long long)n * xcd / 8u);
+        q_end = (uint32_t)((unsigned long long)n * (xcd + 1u) / 8u);
+        chunk_next = min(lo + wx * tune.chunk, q_end); chunk_end = min(lo + (wx + 1) * tune.chunk, q_end);
+        static_end = lo + nwx * tune.chunk;
+        cursor = &b.xcd_cursors[16 * (seg_c >= 0 ? seg_c : seg_s) + (seg_c >= 0 ? 0 : 8) + xcd];
+    }
     bool exhausted = false;                                                                                   // wave-uniform
     uint32_t slot = SLOT_INVALID;
     bool shadow = false;                    // this lane's ray is a Sun-shadow query
@@ -271,13 +284,13 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         unsigned long long idle = __ballot(slot == SLOT_INVALID);
         while (idle && !exhausted) {
             if (chunk_next == chunk_end) {
-                if (static_end >= n) { exhausted = true; break; }
+                if (static_end >= q_end) { exhausted = true; break; }
                 uint32_t base = 0;
                 if (lane_id() == 0) base = atomicAdd(cursor, tune.chunk);
                 base = __shfl(base, 0, 64) + static_end;
-                if (base >= n) { exhausted = true; break; }
+                if (base >= q_end) { exhausted = true; break; }
                 chunk_next = base;
-                chunk_end = min(base + tune.chunk, n);
+                chunk_end = min(base + tune.chunk, q_end);
             }
             uint32_t want = (uint32_t)__popcll(idle), take = min(want, chunk_end - chunk_next);
             uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1));

@@ -15,8 +15,12 @@ W, H = 1920, 1080
 cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
 r = B.Renderer(W, H, cam)
 r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
-r.set_primitives(B.make_prims(S.scene_d()))
-r.set_max_path_segments(8)
+WORKLOAD = os.environ.get("WORKLOAD", "cfg3")  # cfg3 | dragon871k (the tree that leaves the L2s) | cfg2
+if WORKLOAD == "cfg2":
+    cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
+    r.set_camera(cam)
+r.set_primitives(B.make_prims(S.scene_d(660, 660) if WORKLOAD == "dragon871k" else S.scene_p() if WORKLOAD == "cfg2" else S.scene_d()))
+r.set_max_path_segments(4 if WORKLOAD == "cfg2" else 8)
 r.backend.set_mode(int(os.environ.get('GPUART_MODE', '0')))
 r.backend.set_timing(int(os.environ.get('GPUART_TIMING', '0')))
 for _ in range(REPS):
