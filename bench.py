@@ -265,12 +265,12 @@ def main():
         c = be.counters(reset=True)
         be.set_mode(0)
         return [c.rays, c.nodes, c.prim_tests[0], c.prim_tests[1], c.prim_tests[2], c.prim_tests[3], c.segments,
-                c.algorithmic_bytes() + 32 * W * th * K]
+                c.algorithmic_bytes() + 32 * W * th * K, c.rewalks]
 
     counts = torch.tensor(count(1) + count(4), dtype=torch.float64, device=xdev)
     if dist is not None:
         dist.all_reduce(counts)
-    ref, exe = counts[:8].tolist(), counts[8:].tolist()
+    ref, exe = counts[:9].tolist(), counts[9:].tolist()
     rays, nodes, segments, alg_bytes = ref[0], ref[1], ref[6], ref[7]
 
     # ---- warm-up (untimed), then EXACTLY K timed passes ----
@@ -469,6 +469,7 @@ def main():
                                 reference={"nodes": nodes / K, "algorithmic_bytes": alg_bytes / K},
                                 kernel_events=(kernel_ms, launches, elapsed_all))
     roof["source"] = source
+    roof["kernel_ms_summed_per_pass"] = round(kernel_ms / (K * len(reps)), 4)  # HIP events, all repetitions
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample, rank 0, N=1 only ----
     cpu_baseline = None
@@ -534,6 +535,10 @@ def main():
                                         "time: what the images are worth in the reference's own work, not work this run performed",
         "multi_gpu": multi,
         "nodes_per_step": nodes / K, "nodes_executed_per_step": exe[1] / K,
+        "rewalked_queries_per_step": exe[8] / K,
+        "rewalked_queries_note": "closest-hit queries whose nearest-child-first walk could not certify its answer (a loose winner with a runner-up "
+                                 "within the band, an odd box: device_scene.h) and that were walked again in the reference's order; their second walk "
+                                 "is part of nodes_executed_per_step",
         "segments_per_step": segments / K,
         "algorithmic_bytes_per_ray": round(alg_bytes / rays, 1) if rays else None,
         "roofline": roof,

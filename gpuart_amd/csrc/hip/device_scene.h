@@ -685,19 +685,25 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
             en = fmaxf(en, up); ef = fmaxf(ef, up);
         }
         const float band = trav_band(ordered);
-        if (ef != GD_ENTRY_MISS) {
+        const float limit = t.closest * band;
+        // (a child entered beyond the limit is not stacked: the closest hit only ever comes nearer, the pop would skip it —
+        //  GD_ENTRY_MISS is beyond every limit)
+        if (!(ef > limit)) {
             StackEntry e;
             e.ref = ref_f; e.pe = t.entry; e.he = ef;
             st.push(e);
         }
-        if (!(en > t.closest * band)) {  // (GD_ENTRY_MISS is beyond every closest)
+        if (!(en > limit)) {
             trav_enter(t, ref_n, en);
             return;
         }
         trav_pop<false>(t, st, wc, true, band);
         return;
     }
-    if (COUNT || hh) {
+    // (the counting variants stack every upper child: the reference's box test of it is counted where its walk performs it, at
+    //  pop time; otherwise an upper child that is missed, or entered beyond the closest hit — which only ever comes nearer —, need
+    //  not wait on the stack for a pop that would skip it)
+    if (COUNT || (hh && !(eh > t.closest))) {
         StackEntry e;
         e.ref = __float_as_uint(q1.w); e.pe = t.entry; e.he = hh ? eh : GD_ENTRY_MISS;
         st.push(e);
@@ -831,12 +837,13 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         band = trav_band(ordered);
     }
     const bool writer = sub == 0;
-    if (eh != GD_ENTRY_MISS) {
+    const float limit = t.closest * band;
+    if (!(eh > limit)) {  // (as trav_step_box: what a pop would skip is not stacked; GD_ENTRY_MISS is beyond every limit)
         StackEntry s;
         s.ref = ref_hi; s.pe = t.entry; s.he = eh;
         st.push(s, writer);
     }
-    if (el != GD_ENTRY_MISS && !(el > t.closest * band)) {
+    if (!(el > limit)) {
         trav_enter(t, ref_lo, el);
         return;
     }

@@ -612,6 +612,8 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     const bool flat_only = c->lean_kernels && !c->exact_boxes && (c->type_mask & ~(uint32_t)GD_FLAT_TYPES) == 0;  // triangle meshes + discs
     const bool round_only = c->lean_kernels && !c->exact_boxes && !flat_only && (c->type_mask & ~(uint32_t)GD_ROUND_TYPES) == 0;  // spheres + discs
     const bool exact = c->exact_boxes != 0;  // a tree with irregular boxes: the kernel variants with comparison-form box tests
+    // k_run's list entries carry the path slot in RUN_SLOT's bits beside their flags
+    if ((uint64_t)b.n_slots * b.batch > (uint64_t)RUN_SLOT) return fail(GPUART_HIP_ERR_DEVICE, "internal: a run of more path slots than k_run's list entries address");
     const uint32_t chunks = b.n_slots * b.batch / BLOCK;
     const dim3 grid(std::min<uint32_t>(c->run_waves, std::max<uint32_t>(1, chunks)));
     TimedLaunch t;
