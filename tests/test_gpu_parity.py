@@ -1244,18 +1244,29 @@ def test_gather_gives_up_within_its_bound_and_the_context_survives(B, O, monkeyp
         b2.close()
 
 
+def _run_cli(args, what, env=None, timeout=180):
+    """gpuart_cli as a child process; a child that does not end is reported with what it had printed, not as a bare TimeoutExpired."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpuart_amd", "bin", "gpuart_cli")
+    p = subprocess.Popen([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, err = p.communicate()
+        raise AssertionError("gpuart_cli (%s) did not end within %d s; stdout: %s stderr: %s" % (what, timeout, out[-1500:], err[-3000:]))
+    assert p.returncode == 0, "%s: %s" % (what, err[-3000:])
+    return out
+
+
 def test_headless_cli_gather_path(tmp_path):
     """gpuart_cli's multi-GPU read-out (Renderer::GatherRadiance -> gpuart_hip_gather_all over ncclCommInitAll) with the one
     rank a single-GPU box allows == the plain read-back."""
-    import subprocess
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpuart_amd", "bin", "gpuart_cli")
-    base = [exe, "--scene", "box", "--width", "72", "--height", "40", "--mode", "pt", "--spp", "3"]
+    base = ["--scene", "box", "--width", "72", "--height", "40", "--mode", "pt", "--spp", "3"]
     a, b = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
-    out = subprocess.run(base + ["--pfm", a], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    env = dict(os.environ, GPUART_CLI_FORCE_GATHER="1")
-    out = subprocess.run(base + ["--pfm", b], capture_output=True, text=True, timeout=120, env=env)
-    assert out.returncode == 0, out.stderr
+    _run_cli(base + ["--pfm", a], "plain read-back")
+    # (NCCL_DEBUG=WARN: if RCCL's own initialisation ever stalls on a box, its messages are in the failure text)
+    _run_cli(base + ["--pfm", b], "read-out through ncclCommInitAll + gpuart_hip_gather_all", env=dict(os.environ, GPUART_CLI_FORCE_GATHER="1", NCCL_DEBUG="WARN"))
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
