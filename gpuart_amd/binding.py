@@ -194,6 +194,18 @@ def scatter_rows_host(g, tile_rgba, full_rgba):
     return full_rgba
 
 
+def tree_class(quads):
+    """What the uploader decides about a compiled tree, without a device: dict(irregular, disorderly, type_mask); the fast kernels
+    walk nearest-child-first iff neither flag is set."""
+    L = hip_lib()
+    q = np.ascontiguousarray(quads, np.float32)
+    flags = C.c_uint32(0)
+    rc = L.gpuart_hip_test_tree_class(_p(q), C.c_size_t(q.size // 4), C.byref(flags))
+    if rc != 0:
+        raise HipError("gpuart_hip error %d: %s" % (rc, L.gpuart_hip_last_error().decode()))
+    return dict(irregular=bool(flags.value & 1), disorderly=bool(flags.value & 2), type_mask=(flags.value >> 8) & 15)
+
+
 def comm_library():
     """Path of the RCCL library libgpuart_hip resolved its entry points from (dladdr of ncclCommInitRank)."""
     L = hip_lib()

@@ -66,6 +66,9 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #ifndef GD_NEAREST
 #define GD_NEAREST 1
 #endif
+#ifndef GD_NEAREST_DIRECT
+#define GD_NEAREST_DIRECT 0  ///< the persistent direct-lighting kernel too (measured slower: kernels_pipeline.h)
+#endif
 #ifndef GD_NEAREST_BAND
 #define GD_NEAREST_BAND 1.00390625f  ///< 1 + 2^-8 (free up to 2^-8, +2.5 % time at 2^-6: profiles/r04/nearest_child_first.txt)
 #endif

@@ -1229,6 +1229,21 @@ int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, fl
     return 0;
 }
 
+// ---- uploader hook: what gpuart_hip_upload_bvh decides about a tree, without a device (include/gpuart_hip.h) ----------
+int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flags) {
+    if (!quads || !nquads || !flags) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    try {
+        Converter cv;
+        cv.q = quads; cv.nq = nquads;
+        Converter::Child root;
+        if (!cv.convert(root, 1)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
+        *flags = (cv.irregular ? 1u : 0u) | (cv.disorderly ? 2u : 0u) | (cv.type_mask << 8);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(GPUART_HIP_ERR_ARG, std::string("tree: ") + e.what());
+    }
+}
+
 // ---- run planner hook: the planner of the context, driven without a device (include/gpuart_hip.h) ---------------------
 int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_ops, uint32_t *runs, int max_runs) {
     if (!cfg || (!ops && n_ops) || n_ops < 0 || (!runs && max_runs) || max_runs < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");

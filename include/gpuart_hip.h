@@ -232,6 +232,14 @@ int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims,
  * Returns the number of runs (which may exceed max_runs: only the first max_runs are stored), or a negative error. */
 int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_ops, uint32_t *runs, int max_runs);
 
+/* What gpuart_hip_upload_bvh decides about a canonical compiled tree (pure host code: needs no device and no context): *flags =
+ * bit 0: some box is irregular (min > max, NaN or infinite on an axis) — box tests take the reference's comparison form;
+ * bit 1: some box does not bound what it holds by the reference's own formulas (a child outside its parent, a primitive outside its
+ *        leaf's box, a negative radius, cone constants that contradict its centres, coordinates beyond 2^20) — with either bit the
+ *        tree is walked in the reference's order throughout; with neither the fast kernels visit the nearer child first;
+ * bits 8-11: the primitive types present. GPUART_HIP_ERR_ARG for a malformed tree (gpuart_hip_last_error says why). */
+int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flags);
+
 /* The validation every rank of gpuart_hip_gather applies to the exchanged share table (pure host code): `shares[k]` and
  * `status[k]` (0: ready) as rank k announced them. 0 if the gather would go ahead — full-width rows, every frame row covered
  * exactly once, every rank ready — else the error code it would return on every rank (gpuart_hip_last_error says why). */

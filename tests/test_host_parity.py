@@ -307,3 +307,52 @@ def test_cone_constants_equal_reference_vec3_arithmetic():
             if not np.isnan(exp[16:]).any():
                 box = np.concatenate([tree[0, :3], tree[1, :3]]).astype(np.float32)
                 assert (box.view(np.uint32) == exp[16:].view(np.uint32)).all(), "%s cone %d box: got %s expected %s" % (name, i, box, exp[16:])
+
+
+def test_uploader_classifies_trees_for_the_visiting_order():
+    """The fast kernels visit a node's nearer child first only where boxes bound what they hold ("Nearer child
+    first, with a certificate"); gpuart_hip_upload_bvh decides per tree, and gpuart_hip_test_tree_class shows the decision without a
+    device. Every scene of BASELINE.json and of the reference's scene list must come out order-free (or the fast path is silently
+    lost); what the hostile classes produce must not."""
+    from gpuart_amd import binding as B
+    from gpuart_amd import synth_scenes as S
+    T = lambda descs: B.tree_class(B.compile_bvh(descs)[0])
+    for name, descs, mask in (("box", S.box_scene(), 15), ("scene_d", S.scene_d(), 6), ("scene_p", S.scene_p(), 3), ("tree", S.tree_scene(), 11),
+                              ("lattice", S.lattice_scene(), 7), ("one sphere of radius 0", [(S.SPHERE, [0, 0, 1, 0])], 1)):
+        c = T(descs)
+        assert c == dict(irregular=False, disorderly=False, type_mask=mask), (name, c)
+    flagged = 0
+    for seed in range(200):  # the plain random class (degenerate but honest primitives): only its empty scenes are held back
+        prims = S.random_case(seed)["prims"]
+        c = T(prims)
+        assert not c["disorderly"], seed
+        assert c["irregular"] == (len(prims) == 0), seed
+        assert not T(S.random_lattice_case(seed)["prims"])["disorderly"], seed
+        flagged += c["irregular"]
+    assert 0 < flagged < 20
+    floor = (S.DISC, [0, 0, 0, 0, 0, 1, 6])
+    # a box that does not bound its primitive in any useful sense, each for its own reason
+    assert T([floor, (S.SPHERE, [0, 0, 1, -0.5])])["disorderly"]                                  # negative radius (its leaf's box is saved by the floor)
+    assert T([(S.SPHERE, [0, 0, 1, -0.5])])["irregular"]                                          # alone: an inverted box
+    assert T([floor, (S.TRIANGLE, [0, 0, -1e30, 1, 0, 0, 0, 1, 0])])["disorderly"]                # a vertex that swallows the ray origin
+    assert T([floor, (S.TRIANGLE, [0, 0, 0.5, 1, 0, 0.5, 0, 2.0e6, 0.5])])["disorderly"]          # beyond 2^20
+    assert T([floor, (S.SPHERE, [0, 0, 1, 2.0e6])])["disorderly"]
+    assert not T([floor, (S.TRIANGLE, [0, 0, 0.5, 1, 0, 0.5, 0, 1.0e6, 0.5])])["disorderly"]      # large but within bounds
+    for bad in (float("nan"), float("inf")):
+        c = T([floor, (S.SPHERE, [0, bad, 1, 0.5])])
+        assert c["irregular"] or c["disorderly"]
+    c = T([floor, (S.CONE, [0, 0, 0, 0, 0, 1, 0.2, -0.1])])                                       # a cone with a negative radius
+    assert c["irregular"] or c["disorderly"]
+    # a hand-made tree: a child pushed outside its parent, a cone whose axis contradicts its centres
+    tree, _ = B.compile_bvh(S.scene_p())
+    assert not B.tree_class(tree)["disorderly"]
+    hacked = tree.copy(); hacked[3, 0] -= 100.0   # the lower child of the root: bbmin.x far outside
+    assert B.tree_class(hacked) == dict(irregular=False, disorderly=True, type_mask=3)
+    ctree, _ = B.compile_bvh([floor, (S.CONE, [0, 0, 0.2, 0.3, 0.1, 0.9, 0.2, 0.1])])
+    assert not B.tree_class(ctree)["disorderly"]
+    rows = np.nonzero(ctree[:, 0].view(np.uint32) == S.CONE)[0]
+    k = int([r for r in rows if ctree[r, 1] == 0 and ctree[r, 2] == 0][0])  # the cone's type quad; its data quads follow
+    bent = ctree.copy(); bent[k + 3, 0:3] = (1.0, 0.0, 0.0)                # axis no longer points from centre 1 to centre 2
+    assert B.tree_class(bent)["disorderly"]
+    with pytest.raises(B.HipError, match="malformed"):
+        B.tree_class(tree[:5])
