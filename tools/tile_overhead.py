@@ -18,11 +18,15 @@ for n in [int(x) for x in os.environ.get("TILE_N", "1,2,4,8").split(",")]:
         if n > 1:
             y0, rows, band, stride, _ = sharding.interleaved_rows(rank, n, H)
             assert r.set_interleaved_tile(0, y0, W, rows, band, stride)
-        r.restart_path_tracing(1, 3); [r.path_tracing_pass() for _ in range(3)]; r.finish()
-        r.set_seed(5489); r.restart_path_tracing(1, K)
-        t0 = time.perf_counter()
-        for _ in range(K): r.path_tracing_pass()
-        r.finish()
-        worst = max(worst, (time.perf_counter() - t0) / K * 1e3)
+        # one untimed sequence of the timed shape first (the first use of every pass lane costs ~3 ms once: bench.py warms up the same
+        # way), then the best of three timed ones
+        best = 1e9
+        for rep in range(4):
+            r.set_seed(5489); r.restart_path_tracing(1, K)
+            t0 = time.perf_counter()
+            for _ in range(K): r.path_tracing_pass()
+            r.finish()
+            if rep: best = min(best, (time.perf_counter() - t0) / K * 1e3)
+        worst = max(worst, best)
     t1 = t1 or worst
     print("N=%d  %.3f ms/pass (slowest of first/last rank)  speed-up %.2fx  efficiency %.0f%%" % (n, worst, t1 / worst, 100 * t1 / worst / n))
