@@ -21,6 +21,9 @@ if WILD:
 WILD2 = "--wild2" in sys.argv  # the second class of hostile numbers (gpuart_amd.synth_scenes.random_wild2_case)
 if WILD2:
     sys.argv.remove("--wild2")
+LATTICE = "--lattice" in sys.argv  # coplanar / coincident primitives on a coarse lattice: where the answer hinges on the reference's visiting order
+if LATTICE:
+    sys.argv.remove("--lattice")
 
 
 def main():
@@ -29,7 +32,7 @@ def main():
     gl = glref.GLRef()
     progs, bad = {}, 0
     for seed in range(first, first + count):
-        case = S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
+        case = S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
         tree, _ = O.build_bvh(case["prims"])
         ms = case["max_segments"]
         if ms not in progs:
