@@ -380,6 +380,12 @@ class Backend:
         self._chk(self.L.gpuart_hip_scene_info(self.ctx, C.byref(nodes), C.byref(prims), C.byref(depth), C.byref(bytes_)))
         return dict(nodes=nodes.value, prims=prims.value, max_depth=depth.value, device_bytes=bytes_.value)
 
+    def scene_order(self):
+        """0: nearer child first (certified); 1: the reference's order (small tree); 2: the reference's order, exact box tests."""
+        o = C.c_int(-1)
+        self._chk(self.L.gpuart_hip_scene_order(self.ctx, C.byref(o)))
+        return o.value
+
     # test hooks
     def _hook(self, name, ins, nout, *extra):
         ins = [np.ascontiguousarray(a, np.float32) for a in ins]

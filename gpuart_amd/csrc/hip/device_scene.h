@@ -233,6 +233,10 @@ GD_FN float triangle_t(float rox, float roy, float roz, float rdx, float rdy, fl
 /// types is not generated, which is worth 15 VGPRs — a fifth wave per SIMD — in the BVH-query kernel).
 #define GD_ALL_TYPES 0xF
 #define GD_EXACT_BOXES 0x10  ///< beside a type mask: the kernel variant for trees with irregular boxes (box tests in comparison form)
+#define GD_REF_ORDER 0x20    ///< beside a type mask: regular boxes, but every walk keeps the reference's order — small trees, where the
+                             ///< certificate's bookkeeping costs more than the nearer-child-first order saves (Scene P, 273 primitives:
+                             ///< 0.432 against 0.447 ms per pass; profiles/r04/small_trees_keep_the_reference_order.txt)
+#define GD_NEAREST_OF(TYPES) (GD_NEAREST && !((TYPES) & (GD_EXACT_BOXES | GD_REF_ORDER)))
 /// How a kernel tests boxes: the fast (med3) form, the exact comparison form, or whichever Scene::exact_boxes asks for
 /// (kernels off the fast path: one wave-uniform branch per step).
 enum { GD_BOXES_FAST = 0, GD_BOXES_EXACT = 1, GD_BOXES_RUNTIME = 2 };

@@ -111,6 +111,8 @@ struct gpuart_hip_ctx {
     gpuart_params pend_params{};
     int pend_npaths = 0;
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
+    uint32_t ref_order = 0;       ///< a small tree of regular boxes: the fast kernels keep the reference's order (GD_REF_ORDER variants)
+    uint32_t nearest_min_prims = 1024;  ///< GPUART_HIP_NEAREST_MIN_PRIMS: trees with fewer primitives keep the reference's order
     uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
@@ -384,6 +386,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
     c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
     c->tune.xcd_queues = env_u32("GPUART_HIP_XCD_QUEUES", 0, 0, 1);
+    c->nearest_min_prims = env_u32("GPUART_HIP_NEAREST_MIN_PRIMS", 1024, 0, 0x7fffffff);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->plan.lanes_total = (uint32_t)c->lanes.size();
@@ -491,6 +494,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     c->type_mask = cv.type_mask;
     c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
+    c->ref_order = (!c->exact_boxes && c->n_prims < c->nearest_min_prims) ? 1u : 0u;
     c->max_depth = cv.max_depth;
     c->scene_bytes = cv.recs.size() * 16 + cv.prims.size() * 16;
     if ((r = ensure_spill(c))) return r;
@@ -623,16 +627,19 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
         TimedLaunch tt;
         HIP_TRY(hipMemsetAsync(l.run_cursor, 0, sizeof(uint32_t), l.main));
         if (c->timing_level >= 2 && (r = begin_timed(c, tt, 1, l.main))) return r;
-        if (c->plan.mode == 1 && exact) k_run<true, true, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->plan.mode == 1) k_run<true, true, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->plan.mode == 4 && flat_only) k_run<true, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->plan.mode == 4 && exact) k_run<true, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (c->plan.mode == 4) k_run<true, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (flat_only) k_run<false, false, GD_FLAT_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (round_only) k_run<false, false, GD_ROUND_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else if (exact) k_run<false, false, GD_ALL_TYPES | GD_EXACT_BOXES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        else k_run<false, false, GD_ALL_TYPES><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor);
-        HIP_TRY(hipGetLastError());
+#define GD_LAUNCH_RUN(C, R, T) k_run<C, R, T><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor)
+#define GD_LAUNCH_RUN_ORD(C, T) do { if (c->ref_order) GD_LAUNCH_RUN(C, false, (T) | GD_REF_ORDER); else GD_LAUNCH_RUN(C, false, T); } while (0)
+        if (c->plan.mode == 1 && exact) GD_LAUNCH_RUN(true, true, GD_ALL_TYPES | GD_EXACT_BOXES);
+        else if (c->plan.mode == 1) GD_LAUNCH_RUN(true, true, GD_ALL_TYPES);
+        else if (c->plan.mode == 4 && exact) GD_LAUNCH_RUN(true, false, GD_ALL_TYPES | GD_EXACT_BOXES);
+        else if (c->plan.mode == 4 && flat_only) GD_LAUNCH_RUN_ORD(true, GD_FLAT_TYPES);
+        else if (c->plan.mode == 4) GD_LAUNCH_RUN_ORD(true, GD_ALL_TYPES);
+        else if (exact) GD_LAUNCH_RUN(false, false, GD_ALL_TYPES | GD_EXACT_BOXES);
+        else if (flat_only) GD_LAUNCH_RUN_ORD(false, GD_FLAT_TYPES);
+        else if (round_only) GD_LAUNCH_RUN_ORD(false, GD_ROUND_TYPES);
+        else GD_LAUNCH_RUN_ORD(false, GD_ALL_TYPES);
+#undef GD_LAUNCH_RUN_ORD
+#undef GD_LAUNCH_RUN
         if (c->timing_level >= 2 && (r = end_timed(c, tt, l.main))) return r;
     }
     if ((r = end_timed(c, t, l.main))) return r;
@@ -677,10 +684,14 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         TimedLaunch tt;
         int rr;
         if (detail && (rr = begin_timed(c, tt, 1, l.main))) return rr;
-        if (flat_only) k_trace<false, GD_FLAT_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-        else if (round_only) k_trace<false, GD_ROUND_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-        else if (c->exact_boxes) k_trace<false, GD_ALL_TYPES | GD_EXACT_BOXES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
-        else k_trace<false, GD_ALL_TYPES><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune);
+#define GD_LAUNCH_TRACE(T) k_trace<false, T><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune)
+#define GD_LAUNCH_TRACE_ORD(T) do { if (c->ref_order) GD_LAUNCH_TRACE((T) | GD_REF_ORDER); else GD_LAUNCH_TRACE(T); } while (0)
+        if (c->exact_boxes) GD_LAUNCH_TRACE(GD_ALL_TYPES | GD_EXACT_BOXES);
+        else if (flat_only) GD_LAUNCH_TRACE_ORD(GD_FLAT_TYPES);
+        else if (round_only) GD_LAUNCH_TRACE_ORD(GD_ROUND_TYPES);
+        else GD_LAUNCH_TRACE_ORD(GD_ALL_TYPES);
+#undef GD_LAUNCH_TRACE_ORD
+#undef GD_LAUNCH_TRACE
         if (detail && (rr = end_timed(c, tt, l.main))) return rr;
         return 0;
     };
@@ -846,6 +857,12 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
         out->rewalks = h[9];
     }
     if (reset) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
+    return 0;
+}
+
+int gpuart_hip_scene_order(gpuart_hip_ctx *c, int *order) {
+    if (!c || !order || !c->have_scene) return fail(GPUART_HIP_ERR_ARG, "no scene uploaded");
+    *order = c->exact_boxes ? 2 : c->ref_order ? 1 : 0;
     return 0;
 }
 

@@ -120,7 +120,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     // counting variants (their counters are per lane) and by trees with irregular boxes (comparison-form box tests).
     constexpr bool THIN_OK = RUN_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
     // closest-hit queries enter the nearer child first (device_scene.h, GD_NEAREST); the counters of mode 4 count that walk
-    constexpr bool NEAR = GD_NEAREST && !REFWORK && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    constexpr bool NEAR = GD_NEAREST_OF(TYPES) && !REFWORK;
     uint32_t M = 1, sub = 0;                                   // M wave-uniform
     unsigned long long lead = ~0ull;                           // wave-uniform
     __shared__ uint32_t xfer[BLOCK];

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen(Frame f, gpuart_params P, SeedBat
 // LEAF_LANES lanes need it).
 #define GD_FLAT_TYPES ((1 << gd::P_DISC) | (1 << gd::P_TRIANGLE))
 #define GD_ROUND_TYPES ((1 << gd::P_SPHERE) | (1 << gd::P_DISC))  // sphere scenes (Scene P, the cluster): no triangle, no cone code
-#define GD_LEAN_TYPES(T) ((T) == GD_FLAT_TYPES || (T) == GD_ROUND_TYPES)
+#define GD_LEAN_TYPES(T) (((T) & ~GD_REF_ORDER) == GD_FLAT_TYPES || ((T) & ~GD_REF_ORDER) == GD_ROUND_TYPES)
 #ifndef GD_TRACE_WAVES
 #define GD_TRACE_WAVES 5  // waves per SIMD the register allocation must allow (<= 96 VGPRs)
 #endif
@@ -249,7 +249,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     constexpr bool THIN_OK = GD_TRACE_THIN > 1 && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
     // closest-hit queries enter the nearer child first (device_scene.h, GD_NEAREST): fewer node visits; a query whose answer that
     // walk cannot certify goes round again in the reference's order (`refwalk`)
-    constexpr bool NEAR = GD_NEAREST && !COUNT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    constexpr bool NEAR = GD_NEAREST_OF(TYPES) && !COUNT;
     uint32_t M = 1, sub = 0;  // M wave-uniform
     const uint32_t *queue_c = b.queue[seg_c & 1];
     const uint32_t n_c = seg_c >= 0 ? b.counters[4 * seg_c] : 0u;
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
     // Nearer child first (device_scene.h, GD_NEAREST) does not pay here: a frame's primary rays are coherent and half of its queries are
     // Sun-shadow queries, which keep the reference's order anyway — with the certificate's bookkeeping the frame took 0.710 instead of
     // 0.688 ms at 1080p, 1.715 instead of 1.695 at 4K (profiles/r04/direct_lighting_order.txt). GD_NEAREST_DIRECT=1 turns it on.
-    constexpr bool NEAR = GD_NEAREST && GD_NEAREST_DIRECT && GD_BOXES_OF(TYPES) == GD_BOXES_FAST;
+    constexpr bool NEAR = GD_NEAREST_OF(TYPES) && GD_NEAREST_DIRECT;
     uint32_t M = 1, sub = 0;  // M wave-uniform
     const float AMBIENT = 0.15f;
     const F3 sun = f3(P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]);

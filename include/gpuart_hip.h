@@ -216,6 +216,12 @@ int gpuart_hip_kernel_time(gpuart_hip_ctx *ctx, int cls, double *total_ms, uint6
 int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims, uint32_t *max_depth,
                           uint64_t *device_bytes);
 
+/* How the fast kernels walk the uploaded tree: 0 nearer child first with a certificate; 1 in the reference's
+ * order because the tree is small (fewer than GPUART_HIP_NEAREST_MIN_PRIMS primitives, default 1024: the certificate's bookkeeping
+ * costs more than the order saves there); 2 in the reference's order with comparison-form box tests, because a box is irregular or does
+ * not bound its contents (gpuart_hip_test_tree_class). Images are the same bits in all three. */
+int gpuart_hip_scene_order(gpuart_hip_ctx *ctx, int *order);
+
 /* ---- run planner test hook (pure host code: needs no device and no context) ------------------
  * Drives the library's own run planner (csrc/hip/run_planner.h — the code gpuart_hip_resize / _set_share / _pt_plan /
  * _set_mode / _pt_pass / _flush take their scheduling decisions from) through a sequence of operations and reports every

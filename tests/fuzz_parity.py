@@ -37,7 +37,14 @@ if LATTICE:
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    be = B.Backend(0)
+    # two contexts: one that walks every regular tree nearer child first (the kernels of the big scenes), one with the library's
+    # default (trees this small keep the reference's order): every scene goes through both
+    backends = []
+    for knob in ("0", None):
+        if knob is None: os.environ.pop("GPUART_HIP_NEAREST_MIN_PRIMS", None)
+        else: os.environ["GPUART_HIP_NEAREST_MIN_PRIMS"] = knob
+        backends.append(B.Backend(0))
+    os.environ["GPUART_HIP_NEAREST_MIN_PRIMS"] = "0"
     bad = 0
     for seed in range(first, first + count):
         case = S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
@@ -59,54 +66,60 @@ def main():
         if RENDERER:
             # the whole product: Renderer::SetPrimitives builds, compiles and uploads the tree, SetCamera / the Sun setters compute
             # what the oracle computes above, RenderPathTracingPass draws the RandSeeds from its own mt19937
-            r = B.Renderer(W, H, cd)
-            r.set_primitives(prims)
-            r.set_sun(case["sun_az"], case["sun_alt"], case["sun_on"])
-            us = case["user_sphere"]
-            r.set_user_sphere(us[:3], us[3], case["us_em"], bool(flags & 2), bool(flags & 4))
-            r.set_max_path_segments(case["max_segments"])
-            for mode in (0, 3):
-                r.backend.set_mode(mode)
-                r.render_direct(); res["direct", mode] = r.read_direct()
-                r.set_seed(5489 + seed)
-                r.restart_path_tracing(npaths, npaths * K)
-                for k in range(K):
-                    r.path_tracing_pass()
-                res["pt", mode] = r.read_radiance(False)
-            r.close()
+            for which, knob in enumerate(("0", None)):  # nearest-first kernels on every regular tree / the library's default
+                if knob is None: os.environ.pop("GPUART_HIP_NEAREST_MIN_PRIMS", None)
+                else: os.environ["GPUART_HIP_NEAREST_MIN_PRIMS"] = knob
+                r = B.Renderer(W, H, cd)
+                os.environ["GPUART_HIP_NEAREST_MIN_PRIMS"] = "0"
+                r.set_primitives(prims)
+                r.set_sun(case["sun_az"], case["sun_alt"], case["sun_on"])
+                us = case["user_sphere"]
+                r.set_user_sphere(us[:3], us[3], case["us_em"], bool(flags & 2), bool(flags & 4))
+                r.set_max_path_segments(case["max_segments"])
+                for mode in (0, 3):
+                    r.backend.set_mode(mode)
+                    r.render_direct(); res["direct", mode + 10 * which] = r.read_direct()
+                    r.set_seed(5489 + seed)
+                    r.restart_path_tracing(npaths, npaths * K)
+                    for k in range(K):
+                        r.path_tracing_pass()
+                    res["pt", mode + 10 * which] = r.read_radiance(False)
+                r.close()
         elif SHARES:
             # what N ranks do, one after the other on this GPU: every rank renders its share of the FIXED frame (bands of
             # `band` rows dealt round-robin), the shares are scattered into the frame as the gather does on the root
             gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
             rs2 = np.random.RandomState(777 + seed)
             nranks, band = int(rs2.choice([2, 3, 5])), int(rs2.choice([1, 3, 8, 16]))
-            be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
-            for mode in (0, 3):
-                be.set_mode(mode)
-                full_d, full_p = np.zeros((H, W, 4), f32), np.zeros((H, W, 4), f32)
-                for rank in range(nranks):
-                    g = B.share_of_rank(W, H, rank, nranks, band)
-                    if g.th == 0:
-                        continue  # more ranks than bands: nothing to render
-                    be.set_share(g)
-                    be.render_direct(gp); B.scatter_rows_host(g, be.read(0), full_d)
+            for which, be in enumerate(backends):
+                be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
+                for mode in (0, 3):
+                    be.set_mode(mode)
+                    full_d, full_p = np.zeros((H, W, 4), f32), np.zeros((H, W, 4), f32)
+                    for rank in range(nranks):
+                        g = B.share_of_rank(W, H, rank, nranks, band)
+                        if g.th == 0:
+                            continue  # more ranks than bands: nothing to render
+                        be.set_share(g)
+                        be.render_direct(gp); B.scatter_rows_host(g, be.read(0), full_d)
+                        be.pt_reset(); be.pt_plan(K)
+                        for k in range(K):
+                            be.pt_pass(gp, seeds[k], npaths)
+                        B.scatter_rows_host(g, be.read(1), full_p)
+                    res["direct", mode + 10 * which], res["pt", mode + 10 * which] = full_d, full_p
+                be.set_mode(0)
+        else:
+            gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
+            for which, be in enumerate(backends):
+                be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
+                for mode in (0, 2, 3) if which == 0 else (0, 3):  # (mode 2, the megakernel, does not depend on the setting)
+                    be.set_mode(mode)
+                    be.render_direct(gp); res["direct", mode + 10 * which] = be.read(0)
                     be.pt_reset(); be.pt_plan(K)
                     for k in range(K):
                         be.pt_pass(gp, seeds[k], npaths)
-                    B.scatter_rows_host(g, be.read(1), full_p)
-                res["direct", mode], res["pt", mode] = full_d, full_p
-            be.set_mode(0)
-        else:
-            gp = B.Params(); C.memmove(C.byref(gp), C.byref(P), C.sizeof(gp))
-            be.resize(W, H); be.upload_bvh(tree); be.set_camera(cam)
-            for mode in (0, 2, 3):
-                be.set_mode(mode)
-                be.render_direct(gp); res["direct", mode] = be.read(0)
-                be.pt_reset(); be.pt_plan(K)
-                for k in range(K):
-                    be.pt_pass(gp, seeds[k], npaths)
-                res["pt", mode] = be.read(1)
-            be.set_mode(0)
+                    res["pt", mode + 10 * which] = be.read(1)
+                be.set_mode(0)
         ok = True
         for (what, mode), got in res.items():
             exp = exp_direct if what == "direct" else acc
@@ -114,10 +127,11 @@ def main():
                 | (np.isnan(got[..., :3]) & np.isnan(exp[..., :3]))
             if not same.all():
                 ok = False
-                print("seed %d: %s mode %d: %d of %d pixels differ (%d prims, %dx%d, flags %d)"
-                      % (seed, what, mode, int((~same.all(-1)).sum()), W * H, len(prims), W, H, flags), flush=True)
+                print("seed %d: %s mode %d%s: %d of %d pixels differ (%d prims, %dx%d, flags %d)"
+                      % (seed, what, mode % 10, " (default visiting order)" if mode >= 10 else "", int((~same.all(-1)).sum()), W * H, len(prims), W, H, flags), flush=True)
         bad += 0 if ok else 1
-    be.close()
+    for be in backends:
+        be.close()
     print("fuzz: %d scenes, %d with differences" % (count, bad))
     return 1 if bad else 0
 

@@ -286,6 +286,42 @@ def test_deep_tree_spills_the_ring_stack(be, O, B, k0):
         assert_bits(np.concatenate([o0, o1], 1), np.concatenate([e0, e1], 1), "closest hit through the spill path, nearer child first")
 
 
+def test_small_trees_keep_the_reference_order_by_default(B, O, monkeypatch):
+    """The library's own choice (this suite otherwise asks for the nearest-first kernels on every regular tree, tests/conftest.py): a
+    tree of fewer than 1 024 primitives is walked in the reference's order by kernel variants without the certificate's bookkeeping
+    (Scene P: 0.432 instead of 0.447 ms per 1080p pass), a large one nearer child first, an irregular one with exact box tests; the
+    frames are the reference's bits either way."""
+    monkeypatch.delenv("GPUART_HIP_NEAREST_MIN_PRIMS", raising=False)
+    b = B.Backend(0)
+    try:
+        for name, order in (("frames_box_seg5", 1), ("frames_scene_p_seg4", 1), ("frames_scene_pc_seg5", 1), ("frames_tree_seg5", 0), ("frames_scene_d_seg5", 0)):
+            g = golden(name)
+            W, H = int(g["W"]), int(g["H"])
+            tree, _ = O.build_bvh(scene(str(g["scene"])))
+            b.resize(W, H); b.upload_bvh(tree); b.set_camera(g["cam"])
+            assert b.scene_order() == order, name
+            mk = frame_golden_params(O, g)
+            for mode in (0, 3, 5):
+                b.set_mode(mode)
+                b.render_direct(to_params(B, mk()))
+                assert_bits(b.read(0)[..., :3].reshape(-1, 3), g["direct"].reshape(-1, 3), "%s direct, mode %d" % (name, mode))
+                b.pt_reset()
+                b.pt_pass(to_params(B, mk()), g["seeds"][0], 1)
+                assert_bits(b.read(1)[..., :3].reshape(-1, 3), g["pt_pass1"].reshape(-1, 3), "%s first pass, mode %d" % (name, mode))
+        b.set_mode(0)
+        b.upload_bvh(O.build_bvh([(S.SPHERE, [0, 0, 1, -0.5])])[0])
+        assert b.scene_order() == 2
+    finally:
+        b.close()
+    monkeypatch.setenv("GPUART_HIP_NEAREST_MIN_PRIMS", "0")
+    b = B.Backend(0)
+    try:
+        b.upload_bvh(O.build_bvh(scene("box"))[0])
+        assert b.scene_order() == 0
+    finally:
+        b.close()
+
+
 def test_rays_on_which_visiting_order_decides(be, O):
     """Four rays found by tools/order_rays.py among 1.7e9 (tests/golden/order_rays.npz): each meets a box whose entry parameter, as
     the reference computes it, is NOT its slab entry — the face the ray enters through fails its own test by rounding at an

@@ -17,6 +17,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPUART_HIP_NEAREST_MIN_PRIMS", "0")  # the nearest-first kernels also on trees the library would walk in the reference's order (small ones)
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from gpuart_amd import binding as B  # noqa: E402
 from gpuart_amd import synth_scenes as S  # noqa: E402
