@@ -42,10 +42,11 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 // ulps larger. Then the reference's pruning — and so its winner among surfaces that (nearly) coincide — hinges on its order:
 // measured, 3 of 1e9 rays of cfg3 and every tenth scene of coplanar lattice geometry (profiles/r04/nearest_child_first.txt).
 // The fast kernels therefore walk nearest-first WITH a certificate (NEAREST template arguments below):
-//   * pruning is widened by GD_NEAREST_BAND: a node is skipped only if the largest entry parameter on its path exceeds
-//     closest x BAND, so every primitive within the band of the final hit is tested whatever the order;
+//   * pruning is widened by GD_NEAREST_BAND: a node is skipped only if its entry parameter exceeds closest x BAND, so every
+//     primitive within the band of the final hit is tested whatever the order;
 //   * the query tracks the runner-up (second smallest accepted parameter) and whether the winner is "loose": some box on its
-//     path is entered beyond the winner's own parameter (only then can the reference have pruned it);
+//     path is entered beyond the winner's own parameter (only then can the reference have pruned it) — its leaf's box, in fact:
+//     without odd boxes (next item) entry parameters never decrease towards the leaves (aabb_entry);
 //   * a box is "odd" when its reported entry parameter is not its slab entry (aabb_entry): the face the ray enters through failed
 //     its own test by rounding at an edge, the reference's running minimum fell on the face the ray leaves through, and the box
 //     claims to be entered beyond hits that lie inside it — by up to its whole depth; what the reference finds there depends on
@@ -74,9 +75,6 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #endif
 #ifndef GD_CERT_ODD
 #define GD_CERT_ODD 1      // ablation switches of the certificate's parts (tools/ab_build.sh; never 0 in the product build)
-#endif
-#ifndef GD_CERT_PATHMAX
-#define GD_CERT_PATHMAX 1
 #endif
 #ifndef GD_CERT_HITS
 #define GD_CERT_HITS 1
@@ -306,7 +304,10 @@ GD_FN bool aabb_entry_exact(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos)
 
 /// `odd` (fast form, when asked for): the box is hit from outside, but the entry parameter the reference's running minimum
 /// arrives at is NOT the slab entry — the largest of the three axes' nearer plane parameters, which is what it equals, bit
-/// for bit, whenever the face the ray enters through passes its own test. Where rounding fails that face (a ray through an
+/// for bit, whenever the face the ray enters through passes its own test and no face passes early. Boxes that are not odd
+/// therefore report their slab entry, and slab entries never decrease from a box to a box nested in it (the uploader checks the
+/// nesting: converter.h): fp32 subtraction, multiplication by the ray's 1/d, min and max are all monotone. That is what lets a
+/// walk take the entry parameter of a leaf for the largest one on the path to it (take_hit's `loose`). Where rounding fails that face (a ray through an
 /// edge or a corner) the minimum falls on the face the ray LEAVES through: the box then reports an entry parameter larger than
 /// hits inside it by up to its whole depth, and what the reference finds in it depends on when its walk gets there
 /// (1 ray in ~1e8; device_scene.h top, trav_settle).
@@ -330,7 +331,7 @@ GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos, bool 
     pos = inside ? -1.0f : fminf(best, 1.0e+19f);
     if (WITH_ODD) {
         const float slab = fmaxf(fmaxf(fminf(k0, k1), fminf(k2, k3)), fminf(k4, k5));
-        *odd = !inside & hit & (best > slab);
+        *odd = !inside & hit & (best != slab);  // (NaN parameters — a ray component of exactly 0 on a box plane — compare unequal: odd)
     }
     return inside | hit;
 }
@@ -340,7 +341,7 @@ struct Trav {
     float closest;
     uint32_t hit_prim;   ///< (| GD_PRIM_LOOSE during a NEAREST walk; trav_settle removes it)
     uint32_t node;       ///< DESCEND: record to fetch; LEAF: first primitive index
-    float entry;         ///< box-entry parameter of the node entered last; in an ordered NEAREST walk the largest one on the path to it
+    float entry;         ///< box-entry parameter of the node entered last (on a path without odd boxes also the largest one on the path: aabb_entry)
     int state;
     float second;        ///< NEAREST walks: parameter of the runner-up (1e19: none)
 };
@@ -557,7 +558,7 @@ GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
 }
 
 /// Returns to the nearest pending upper child that is still worth visiting (or finishes).
-/// `band`: 1 in the reference's order; GD_NEAREST_BAND in an ordered NEAREST walk, whose entries are path maxima (trav_step_box).
+/// `band`: 1 in the reference's order; GD_NEAREST_BAND in an ordered NEAREST walk.
 template <bool COUNT>
 GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true, float band = 1.0f) {
     const float limit = t.closest * band;  // (x 1.0f is exact)
@@ -591,8 +592,9 @@ GD_FN bool trav_settle(Trav &t, bool ordered) {
     return again;
 }
 
+/// `certify`: the walk that follows is an ordered NEAREST one — an odd root box (aabb_entry) marks the query like any other odd box.
 template <int BOXES = GD_BOXES_RUNTIME>
-GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool count) {
+GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool count, bool certify = false) {
     t.closest = 1e+19f;
     t.second = 1e+19f;
     t.hit_prim = GD_NO_PRIM;
@@ -610,7 +612,11 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
         hit = aabb_entry<true>(r, rdiv, bmin, bmax, entry);
     } else {
         const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
-        if (__ballot(!inside) != 0) hit = aabb_entry(r, rdiv, bmin, bmax, entry);
+        if (__ballot(!inside) != 0) {
+            bool odd = false;
+            hit = aabb_entry<false, true>(r, rdiv, bmin, bmax, entry, &odd);
+            if (certify & odd) t.second = -__builtin_inff();
+        }
     }
     if (hit) trav_enter(t, sc.root_ref, entry);  // entry > 1e19 cannot happen
     else t.state = TRAV_DONE;
@@ -631,8 +637,8 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
 
 /// One interior-node visit: fetch its record, test both children's boxes, descend / stack / pop.
 /// Precondition: state == DESCEND.
-/// NEAREST (fast kernels, regular boxes): the child whose box is entered first is visited first, its entry parameter raised to
-/// the largest one on the path (what take_hit / trav_pop compare) and pruning widened by the band; `ordered` = false keeps this
+/// NEAREST (fast kernels, regular boxes): the child whose box is entered first is visited first, pruning is widened by the band
+/// and odd boxes mark the query; `ordered` = false keeps this
 /// lane's query in the reference's order to the letter (a Sun-shadow query, a query trav_settle sent round again). Both box
 /// tests of the record count as performed.
 template <bool COUNT, int BOXES = GD_BOXES_RUNTIME, bool NEAREST = false>
@@ -695,10 +701,8 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
             const float ee = en; en = ef; ef = ee;
         }
         // an ordered walk carries the largest entry parameter of the path (t.entry is this node's)
-        if (GD_CERT_PATHMAX) {
-            const float up = ordered ? t.entry : -__builtin_inff();
-            en = fmaxf(en, up); ef = fmaxf(ef, up);
-        }
+        // (no path maxima are carried: on a path without odd boxes — and a query that meets one is walked again — entry parameters
+        //  never decrease towards the leaves, see aabb_entry; a leaf's own is the largest)
         const float band = trav_band(ordered);
         const float limit = t.closest * band;
         // (a child entered beyond the limit is not stacked: the closest hit only ever comes nearer, the pop would skip it —
@@ -819,7 +823,7 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         if (NEAREST) {  // aabb_entry's `odd`: the box is entered beyond its slab entry (the partner lane holds the other plane of every axis)
             const float slab = fmaxf(fmaxf(fminf(kx, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(kx)), fminf(ky, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(ky))),
                                      fminf(kz, quad_f<GD_QUAD_PERM(1, 0, 3, 2)>(kz)));
-            const uint32_t odd = (!inside & (best < INF) & (best > slab)) ? 1u : 0u;
+            const uint32_t odd = (!inside & (best < INF) & (best != slab)) ? 1u : 0u;
             if (ordered & ((odd | quad_u<GD_QUAD_PERM(2, 3, 0, 1)>(odd)) != 0)) t.second = -INF;
         }
         ref_lo = quad_u<GD_QUAD_PERM(0, 0, 0, 0)>(__float_as_uint(mine.w));
@@ -845,12 +849,7 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         const uint32_t rr = ref_lo; ref_lo = ref_hi; ref_hi = rr;
         const float ee = el; el = eh; eh = ee;
     }
-    float band = 1.0f;
-    if (NEAREST) {  // as trav_step_box: path maxima and the band in an ordered walk
-        const float up = ordered ? t.entry : -INF;
-        el = fmaxf(el, up); eh = fmaxf(eh, up);
-        band = trav_band(ordered);
-    }
+    const float band = NEAREST ? trav_band(ordered) : 1.0f;
     const bool writer = sub == 0;
     const float limit = t.closest * band;
     if (!(eh > limit)) {  // (as trav_step_box: what a pop would skip is not stacked; GD_ENTRY_MISS is beyond every limit)
@@ -913,7 +912,7 @@ GD_FN void traverse(const Scene &sc, const Ray &r, TravStack &st, float &closest
     constexpr int BOXES = NEAREST ? GD_BOXES_FAST : GD_BOXES_RUNTIME;
     bool ordered = true;
     for (;;) {
-        trav_init<BOXES>(sc, r, rdiv, t, st, wc, COUNT && ordered);
+        trav_init<BOXES>(sc, r, rdiv, t, st, wc, COUNT && ordered, NEAREST && ordered);
         while (t.state != TRAV_DONE) {
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT, BOXES, NEAREST>(sc, r, rdiv, t, st, wc, ordered);
             else trav_step_leaf<ANY_HIT, COUNT, GD_ALL_TYPES, NEAREST>(sc, r, t, st, wc, ordered);

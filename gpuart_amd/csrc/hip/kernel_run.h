@@ -333,7 +333,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
         if (start) {
             rd = (ent & RUN_F_SHADOW) ? sun : xyz(b.ray_d[ent & RUN_SLOT]);
             rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-            trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
+            trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT, NEAR && !(ent & RUN_F_SHADOW));
         }
         if (__ballot(ent != SLOT_INVALID) == 0) break;  // nothing in flight; PRODUCE could not make anything: all done
 

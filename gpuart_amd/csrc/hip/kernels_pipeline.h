@@ -305,7 +305,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                     ro = xyz(b.ray_o[s]);
                     rd = sh ? sun : xyz(b.ray_d[s]);
                     rdiv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
-                    trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT);
+                    trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, COUNT, NEAR && !sh);
                 }
             }
             chunk_next += take;
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
         ro = o; rd = d;
         refwalk = false;
         rdiv = f3(1 / d.x, 1 / d.y, 1 / d.z);
-        trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false);
+        trav_init<GD_BOXES_OF(TYPES)>(sc, Ray{ro, rd}, rdiv, t, st, &wc, false, NEAR && stage != DL_SUN);
     };
 
     for (;;) {
