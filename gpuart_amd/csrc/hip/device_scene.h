@@ -350,7 +350,7 @@ struct Trav {
 /// primitives in address order and keeps the strictly closer one (shaders/bvh_intersection.glsl:416). A NEAREST walk gets the same
 /// winner in any order by letting the lower index win equal parameters (signed compare: GD_NO_PRIM = -1 never loses a tie it
 /// cannot have — closest starts at 1e19 and a hit AT 1e19 is not accepted by the reference's `<` either), and keeps what
-/// trav_settle needs: the runner-up's parameter and whether the winner is loose (t.entry, the largest entry parameter on the path
+/// trav_settle needs: the runner-up's parameter and whether the winner is loose (t.entry, the entry parameter of this leaf's box — the largest on the path
 /// to this leaf, exceeds its parameter).
 template <bool NEAREST>
 GD_FN bool take_hit(Trav &t, float pos, uint32_t pi) {
@@ -700,7 +700,6 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
             const uint32_t rr = ref_n; ref_n = ref_f; ref_f = rr;
             const float ee = en; en = ef; ef = ee;
         }
-        // an ordered walk carries the largest entry parameter of the path (t.entry is this node's)
         // (no path maxima are carried: on a path without odd boxes — and a query that meets one is walked again — entry parameters
         //  never decrease towards the leaves, see aabb_entry; a leaf's own is the largest)
         const float band = trav_band(ordered);
