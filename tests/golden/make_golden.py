@@ -500,6 +500,7 @@ class RefRenderer:
 def scene_tree(name):
     prims = {"box": S.box_scene, "scene_p": S.scene_p, "scene_d": S.scene_d, "cluster": S.cluster_scene, "tree": S.tree_scene,
              "dragon871k": lambda: S.scene_d(660, 660),
+             "lattice": S.lattice_scene, "lattice_big": lambda: S.lattice_scene(seed=5, n=3000),
              "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64)}[name]()
     tree, depth = O.build_bvh(prims)
     return prims, tree, depth
@@ -745,6 +746,29 @@ def gen_cluster_tree(gl):
                  bvh_depth=depth, **out)
 
 
+def gen_lattice(gl):
+    """Scenes of coplanar, overlapping axis-aligned triangles and discs and coincident spheres (synth_scenes.lattice_scene): which of
+    two coincident surfaces a ray reports hinges on the order in which the reference's walk meets them. 401 and 3 001 primitives,
+    direct lighting + two path-tracing passes (+ one pass of 3 paths for the small one), 128x72, default camera.
+    The large scene's tree is 402 levels deep (its primitives' box centres tie all the time) and a ray walks thousands of nodes:
+    with 3 paths per pass a fragment exceeds 65 535 loop iterations, where llvmpipe (gallivm's loop limiter: one budget for all loops
+    of a shader invocation) breaks the reference's traversal loop off — the frame is then llvmpipe's, not the reference's (measured:
+    0 / 101 / 2 361 of 9 216 pixels differ from the oracle with 1 / 2 / 3 paths per pass, oracle/README.md). Fixtures stay below."""
+    seeds = O.randseeds(16)
+    progs = RefPrograms(gl)
+    for name in ("lattice", "lattice_big"):
+        _, tree, depth = scene_tree(name)
+        r = RefRenderer(gl, progs, 128, 72, default_cam(S.DEFAULT_CAMERA), tree)
+        out = {"direct": r.direct()[..., :3].copy()}
+        r.reset()
+        out["pt_pass1"] = r.pt_pass(1, seeds[0])[..., :3].copy()
+        out["pt_acc"] = r.pt_pass(1, seeds[1])[..., :3].copy()
+        if name == "lattice":
+            r.reset()
+            out["pt_3paths"] = r.pt_pass(3, seeds[0])[..., :3].copy()
+        save("frames_%s_seg5" % name, scene=name, W=128, H=72, cam=r.cam, max_segments=5, npasses=2, seeds=seeds, bvh_depth=depth, **out)
+
+
 def gen_dragon871k(gl):
     """The reference's largest scene as a stand-in of its size (main.cpp:321 "dragon 871k": 871 200 triangles; here the displaced torus
     at 660 x 660 quads + floor disc; 75 MB of tree on the device, which no longer fits the L2s): benchmark camera, depth 8,
@@ -760,7 +784,7 @@ def gen_dragon871k(gl):
     save("frames_dragon871k_seg8", scene="dragon871k", W=128, H=72, cam=r.cam, max_segments=8, npasses=2, seeds=seeds, bvh_depth=depth, **out)
 
 
-SECTIONS = dict(dragon871k=gen_dragon871k, scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
+SECTIONS = dict(dragon871k=gen_dragon871k, lattice=gen_lattice, scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
                 disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, order_rays=gen_order_rays, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 

@@ -27,6 +27,8 @@ SCENES = {
     "tree": S.tree_scene,
     "dragon871k": lambda: S.scene_d(660, 660),
     "scene_pc": lambda: S.scene_p(seed=3, nspheres=96, ndiscs=24, ncones=64),
+    "lattice": S.lattice_scene,                               # coplanar / coincident primitives: the visiting order decides (round 4)
+    "lattice_big": lambda: S.lattice_scene(seed=5, n=3000),   # ... on a tree large enough for the nearest-first kernels by default
 }
 
 
