@@ -23,10 +23,11 @@ from gpuart_amd import binding as B  # noqa: E402
 from gpuart_amd import synth_scenes as S  # noqa: E402
 
 
-def make(workload, W, H, mode, tmpdir):
+def make(workload, W, H, mode, tmpdir, camera=None):
     cams = {"cfg3": S.BENCH_CAMERA, "dragon871k": S.BENCH_CAMERA, "cfg2": S.DEFAULT_CAMERA, "box": S.DEFAULT_CAMERA, "lattice": S.DEFAULT_CAMERA,
             "cluster": S.CLUSTER_NEAR_CAMERA, "tree": S.TREE_NEAR_CAMERA}
-    cam = dict(cams[workload]); cam["dir"] = S.camera_dir(cam)
+    cam = dict({"default": S.DEFAULT_CAMERA, "bench": S.BENCH_CAMERA, "cluster": S.CLUSTER_NEAR_CAMERA, "tree": S.TREE_NEAR_CAMERA}[camera] if camera else cams[workload])
+    cam["dir"] = S.camera_dir(cam)
     r = B.Renderer(W, H, cam)
     r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
     segs = 5
@@ -56,10 +57,11 @@ def main():
     ap.add_argument("--passes", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--mode", type=int, default=0)
+    ap.add_argument("--camera", choices=["default", "bench", "cluster", "tree"], default=None, help="another camera than the workload's own")
     a = ap.parse_args()
     W, H = (int(x) for x in a.frame.split("x"))
     with tempfile.TemporaryDirectory() as tmp:
-        fast, ref = make(a.workload, W, H, a.mode, tmp), make(a.workload, W, H, 1, tmp)
+        fast, ref = make(a.workload, W, H, a.mode, tmp, a.camera), make(a.workload, W, H, 1, tmp, a.camera)
         fast.render_direct(); ref.render_direct()
         d = int((fast.read_direct()[..., :3].view(np.uint32) != ref.read_direct()[..., :3].view(np.uint32)).any(-1).sum())
         print("%s %dx%d: direct lighting: %d differing pixels" % (a.workload, W, H, d), flush=True)
@@ -85,8 +87,8 @@ def main():
                 ys, xs = np.nonzero(bad)
                 msg = "  first: pixel (%d, %d) fast %s reference-order %s" % (xs[0], ys[0], out[0][ys[0], xs[0], :3], out[1][ys[0], xs[0], :3])
             print("chunk %d: %d passes, %d differing pixels%s" % (c, a.passes, int(bad.sum()), msg), flush=True)
-        print("%s %dx%d mode %d vs mode 1: %d passes, %.3g reference-defined rays, %d differing pixel-chunks; %.3f / %.3f ms per pass (fast / reference order)"
-              % (a.workload, W, H, a.mode, a.passes * a.chunks, rays, total_bad, t_fast / (a.passes * a.chunks) * 1e3, t_ref / (a.passes * a.chunks) * 1e3), flush=True)
+        print("%s%s %dx%d mode %d vs mode 1: %d passes, %.3g reference-defined rays, %d differing pixel-chunks; %.3f / %.3f ms per pass (fast / reference order)"
+              % (a.workload, " (%s camera)" % a.camera if a.camera else "", W, H, a.mode, a.passes * a.chunks, rays, total_bad, t_fast / (a.passes * a.chunks) * 1e3, t_ref / (a.passes * a.chunks) * 1e3), flush=True)
         fast.close(); ref.close()
     return 1 if total_bad or d else 0
 
