@@ -1174,6 +1174,7 @@ def test_headless_cli_resume_continues_to_more_paths(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+@pytest.mark.rccl
 def test_rccl_gather_with_one_rank(B, be, O):
     """The gather of include/gpuart_hip.h on real RCCL, as far as one GPU allows: communicator of one rank (ncclGetUniqueId,
     ncclCommInitRank through dlopen; ncclCommCount / ncclCommUserRank read back), exchange of share + status (ncclAllGather), empty
@@ -1236,6 +1237,7 @@ def test_rccl_gather_with_one_rank(B, be, O):
         be.resize(W, H)
 
 
+@pytest.mark.rccl
 def test_gather_gives_up_within_its_bound_and_the_context_survives(B, O, monkeypatch):
     """The exchange of the shares cannot complete (one GPU: the stream is held by gpuart_hip_test_stall, as a peer that never
     arrives would hold it): gpuart_hip_gather must come back with GPUART_HIP_ERR_TIMEOUT within GPUART_HIP_GATHER_TIMEOUT_MS — it
@@ -1295,6 +1297,7 @@ def _run_cli(args, what, env=None, timeout=180):
     return out
 
 
+@pytest.mark.rccl
 def test_headless_cli_gather_path(tmp_path):
     """gpuart_cli's multi-GPU read-out (Renderer::GatherRadiance -> gpuart_hip_gather_all over ncclCommInitAll) with the one
     rank a single-GPU box allows == the plain read-back."""
@@ -1306,6 +1309,7 @@ def test_headless_cli_gather_path(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+@pytest.mark.rccl
 def test_frame_sharded_over_several_gpus_equals_the_single_gpu_frame(tmp_path):
     """Where the box has more than one GPU (the driver's 8-GPU node; a one-GPU box skips): gpuart_cli --gpus N renders one frame
     as N interleaved shares on N devices and gathers it through RCCL inside the library (ncclCommInitAll, share + status
