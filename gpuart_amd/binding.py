@@ -349,6 +349,30 @@ class Backend:
         """finish() with a bound: HipError with code ERR_TIMEOUT if the context's work is not complete after timeout_ms."""
         self._chk(self.L.gpuart_hip_wait(self.ctx, C.c_uint32(int(timeout_ms))))
 
+    def test_tile_order(self, order):
+        """Birth order of the paths of a pass: a permutation of the tile's 8x8 pixel blocks (None: row-major)."""
+        if order is None:
+            self._chk(self.L.gpuart_hip_test_tile_order(self.ctx, None, C.c_size_t(0)))
+            return
+        o = np.ascontiguousarray(order, np.uint32)
+        self._chk(self.L.gpuart_hip_test_tile_order(self.ctx, o.ctypes.data_as(C.c_void_p), C.c_size_t(o.size)))
+
+    def test_current_tile_order(self):
+        """The birth order in use (None: row-major)."""
+        g = self.get_share()
+        out = np.empty(((g.tw + 7) // 8) * ((g.th + 7) // 8), np.uint32)
+        rc = self.L.gpuart_hip_test_current_tile_order(self.ctx, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size))
+        if rc < 0:
+            self._chk(rc)
+        return out if rc == 1 else None
+
+    def test_sort_tiles(self, cost):
+        """k_tile_order alone: per-block cost -> birth order (most expensive class first, row-major within a class)."""
+        cst = np.ascontiguousarray(cost, np.uint32)
+        out = np.empty(cst.size, np.uint32)
+        self._chk(self.L.gpuart_hip_test_sort_tiles(self.ctx, cst.ctypes.data_as(C.c_void_p), C.c_size_t(cst.size), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def test_stall(self, ms):
         """Keeps the context's primary stream busy for `ms` milliseconds (what a missing peer looks like to the bounded waits)."""
         self._chk(self.L.gpuart_hip_test_stall(self.ctx, C.c_uint32(int(ms))))

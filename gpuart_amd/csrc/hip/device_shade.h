@@ -14,6 +14,10 @@ struct Frame {
                                       ///<  with other contexts for load balance)
     float cam_pos[3], bottom_left[3], delta_horz[3], delta_vert[3];
     float uv_coef[12];         ///< llvmpipe plane equations of the quad's UV (A.u A.v B.u B.v)
+    const uint32_t *tile_order;  ///< null, or a permutation of the tile's 8x8 pixel blocks: path slots [64 k, 64 k + 64) hold block
+                                 ///< tile_order[k] (kernels_pipeline.h slot_pixel) — the order paths are BORN in; no pixel depends on it
+    uint32_t *tile_cost;         ///< null, or per 8x8 block (row-major number) a counter: this run adds one per shaded path segment
+                                 ///< (kernels_pipeline.h tile_cost_add; k_tile_order turns the counts into the next tile_order)
 };
 
 /// Frame row of local row `ly` of the tile.

@@ -96,6 +96,17 @@ struct gpuart_hip_ctx {
     float4 *d_recs = nullptr, *d_prims = nullptr;
     uint32_t *d_cursor = nullptr;  ///< pixel cursor of k_direct_persistent
     uint4 *d_spill = nullptr;      ///< [spill_levels][grid_lanes] traversal-stack overflow for kernels on the primary stream
+    // Birth order of the paths of a run (Frame::tile_order, k_tile_order): the tile's 8x8 blocks, most expensive first. The first run
+    // after the tile was (re)allocated — and the first after every change of camera or scene — counts the shaded segments per block
+    // (`gathers`), a sort behind it writes the buffer that is not in use, and the runs launched once that has finished use it.
+    uint32_t *d_tile_order[2] = {nullptr, nullptr};
+    uint32_t *d_tile_cost = nullptr;
+    hipEvent_t ev_order = nullptr;     ///< the sort into d_tile_order[order_next] has finished
+    int order_cur = -1, order_next = 0; ///< buffer in use (-1: none yet, row-major), buffer being written
+    bool order_sorting = false;        ///< a gathering run + sort is under way
+    bool order_stale = true;           ///< the order in use (or none) was not counted with this camera / scene
+    bool order_auto = true;            ///< GPUART_HIP_TILE_ORDER (default 1)
+    bool order_from_hook = false;      ///< gpuart_hip_test_tile_order set Frame::tile_order: it stays until the hook clears it
     std::vector<PassLane> lanes;
     uint32_t next_lane = 0;
     uint32_t spill_levels = 0;
@@ -166,6 +177,10 @@ int realloc_tile(gpuart_hip_ctx *c) {
     if (r) return r;
     if ((r = drain(c))) return r;
     c->empty_share = false;
+    for (auto &o : c->d_tile_order) if (o) { (void)hipFree(o); o = nullptr; }
+    if (c->d_tile_cost) { (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr; }
+    c->frame.tile_order = nullptr; c->frame.tile_cost = nullptr;
+    c->order_cur = -1; c->order_sorting = false; c->order_stale = true; c->order_from_hook = false;
     if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; }
     if (c->d_accum) { (void)hipFree(c->d_accum); c->d_accum = nullptr; }
     c->plan.tile_pixels = (size_t)c->frame.tw * c->frame.th;
@@ -386,6 +401,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.leaf_lanes = env_u32("GPUART_HIP_LEAF_LANES", 16, 1, 64);
     c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
     c->tune.xcd_queues = env_u32("GPUART_HIP_XCD_QUEUES", 0, 0, 1);
+    c->order_auto = env_u32("GPUART_HIP_TILE_ORDER", 1, 0, 1) != 0;
     c->nearest_min_prims = env_u32("GPUART_HIP_NEAREST_MIN_PRIMS", 1024, 0, 0x7fffffff);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
@@ -430,8 +446,9 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     }
     if (c->comm && c->comm_owned && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
     void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor,
-                    c->d_send, c->d_stage, c->d_hello};
+                    c->d_send, c->d_stage, c->d_hello, c->d_tile_order[0], c->d_tile_order[1], c->d_tile_cost};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->h_hello) (void)hipHostFree(c->h_hello);  // (after drain: no copy into it is queued any more)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -499,12 +516,14 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     c->scene_bytes = cv.recs.size() * 16 + cv.prims.size() * 16;
     if ((r = ensure_spill(c))) return r;
     c->have_scene = true;
+    c->order_stale = true;
     return 0;
 }
 
 int gpuart_hip_set_camera(gpuart_hip_ctx *c, const float pos[3], const float bl[3], const float dh[3], const float dv[3]) {
     if (!c || !pos || !bl || !dh || !dv) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     { int fr = gpuart_hip_flush(c); if (fr) return fr; }  // batched passes were requested with the old camera
+    c->order_stale = true;  // the blocks' cost is counted again by the next run (run_frame)
     memcpy(c->frame.cam_pos, pos, 12); memcpy(c->frame.bottom_left, bl, 12);
     memcpy(c->frame.delta_horz, dh, 12); memcpy(c->frame.delta_vert, dv, 12);
     c->have_camera = true;
@@ -602,6 +621,49 @@ static uint32_t segment_bound(const gpuart_hip_ctx *c, const gpuart_params *p) {
 
 extern "C++" {
 namespace {
+/// The frame as the kernels of ONE run see it: with the birth order of its paths (one order for all launches of the run: path
+/// slots keep their pixels from launch to launch) and, if this run is to count the cost of the tile's blocks, the counters.
+/// The library orders by itself only where that was measured to pay (profiles/r04/birth_order.txt): runs of ONE pass through k_run
+/// — the frame-by-frame use, where the run's tail is a third of its time. Longer runs keep the row-major order: most expensive
+/// first shortens their (relatively smaller) tail too but puts all heavy blocks in flight at once, which costs the main phase more.
+int run_frame(gpuart_hip_ctx *c, Frame &f, bool &gathers, bool single_pass_run) {
+    f = c->frame;
+    gathers = false;
+    if (c->order_from_hook || !c->order_auto || !single_pass_run || (c->plan.mode != 0 && c->plan.mode != 5)) return 0;
+    if (c->order_sorting && hipEventQuery(c->ev_order) == hipSuccess) {  // (hipErrorNotReady: keep the order in use a little longer)
+        c->order_cur = c->order_next;
+        c->order_sorting = false;
+    }
+    (void)hipGetLastError();
+    f.tile_order = c->order_cur >= 0 ? c->d_tile_order[c->order_cur] : nullptr;
+    if (!c->order_sorting && c->order_stale) {
+        const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
+        if (!c->d_tile_cost) {
+            HIP_TRY(hipMalloc(&c->d_tile_cost, tiles * sizeof(uint32_t)));
+            HIP_TRY(hipMemset(c->d_tile_cost, 0, tiles * sizeof(uint32_t)));  // (k_tile_order zeroes what it has read)
+            for (auto &o : c->d_tile_order) if (!o) HIP_TRY(hipMalloc(&o, tiles * sizeof(uint32_t)));
+            if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+        }
+        f.tile_cost = c->d_tile_cost;
+        gathers = true;
+    }
+    return 0;
+}
+
+/// Behind a gathering run on its lane's stream: the sort into the order buffer that no run uses — none launched so far may still
+/// read it (the lanes' ev_done), and the runs to come take it only once ev_order has been seen complete (run_frame).
+int sort_tile_order(gpuart_hip_ctx *c, PassLane &l) {
+    for (auto &o : c->lanes) if (&o != &l && o.used) HIP_TRY(hipStreamWaitEvent(l.main, o.ev_done, 0));
+    c->order_next = c->order_cur == 0 ? 1 : 0;
+    const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
+    k_tile_order<<<1, TO_THREADS, 0, l.main>>>(c->d_tile_cost, c->d_tile_order[c->order_next], (uint32_t)tiles);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_order, l.main));
+    c->order_sorting = true;
+    c->order_stale = false;
+    return 0;
+}
+
 /// The collected passes [first, first + count) as ONE persistent kernel per path of the pass (k_run, kernel_run.h) on
 /// pass lane `l`; then their colour planes are added to the accumulator in pass order on the primary stream.
 int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t count) {
@@ -621,13 +683,16 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     const uint32_t chunks = b.n_slots * b.batch / BLOCK;
     const dim3 grid(std::min<uint32_t>(c->run_waves, std::max<uint32_t>(1, chunks)));
     TimedLaunch t;
+    Frame fr;
+    bool gathers;
+    if ((r = run_frame(c, fr, gathers, count == 1))) return r;
     if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous run has been accumulated
     if ((r = begin_timed(c, t, 0, l.main))) return r;
     for (int j = 0; j < npaths; j++) {
         TimedLaunch tt;
         HIP_TRY(hipMemsetAsync(l.run_cursor, 0, sizeof(uint32_t), l.main));
         if (c->timing_level >= 2 && (r = begin_timed(c, tt, 1, l.main))) return r;
-#define GD_LAUNCH_RUN(C, R, T) k_run<C, R, T><<<grid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor)
+#define GD_LAUNCH_RUN(C, R, T) k_run<C, R, T><<<grid, BLOCK, 0, l.main>>>(sc, fr, *p, seeds, b, j, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune, l.run_cursor)
 #define GD_LAUNCH_RUN_ORD(C, T) do { if (c->ref_order) GD_LAUNCH_RUN(C, false, (T) | GD_REF_ORDER); else GD_LAUNCH_RUN(C, false, T); } while (0)
         if (c->plan.mode == 1 && exact) GD_LAUNCH_RUN(true, true, GD_ALL_TYPES | GD_EXACT_BOXES);
         else if (c->plan.mode == 1) GD_LAUNCH_RUN(true, true, GD_ALL_TYPES);
@@ -648,6 +713,7 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     k_accumulate<<<dim3((unsigned)((c->plan.tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->plan.tile_pixels, b.batch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(l.ev_free, c->stream));
+    if (gathers && (r = sort_tile_order(c, l))) return r;
     l.used = true;
     return 0;
 }
@@ -677,6 +743,9 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     const dim3 pgrid(c->grid_waves);
     const dim3 sgrid(std::min<uint32_t>(c->shade_waves, b.n_slots * b.batch / BLOCK));  // k_gen / k_shade: grid-stride loops
     int j_cur = 0;
+    Frame fr;
+    bool gathers;
+    if ((r = run_frame(c, fr, gathers, false))) return r;  // (an order set through gpuart_hip_test_tile_order applies here too)
     if (l.used) HIP_TRY(hipStreamWaitEvent(l.main, l.ev_free, 0));  // the lane's previous pass has been accumulated
     if ((r = begin_timed(c, t, 0, l.main))) return r;
     // one BVH-query launch: closest-hit queries of segment seg_c and / or Sun-shadow queries of segment seg_s
@@ -684,7 +753,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         TimedLaunch tt;
         int rr;
         if (detail && (rr = begin_timed(c, tt, 1, l.main))) return rr;
-#define GD_LAUNCH_TRACE(T) k_trace<false, T><<<pgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune)
+#define GD_LAUNCH_TRACE(T) k_trace<false, T><<<pgrid, BLOCK, 0, l.main>>>(sc, fr, *p, b, seg_c, seg_s, 1, j_cur, npaths, l.passcolor, l.spill_main, c->d_counters, c->tune)
 #define GD_LAUNCH_TRACE_ORD(T) do { if (c->ref_order) GD_LAUNCH_TRACE((T) | GD_REF_ORDER); else GD_LAUNCH_TRACE(T); } while (0)
         if (c->exact_boxes) GD_LAUNCH_TRACE(GD_ALL_TYPES | GD_EXACT_BOXES);
         else if (flat_only) GD_LAUNCH_TRACE_ORD(GD_FLAT_TYPES);
@@ -699,10 +768,10 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
         j_cur = j;
         HIP_TRY(hipMemsetAsync(b.counters, 0, 4 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
         if (c->tune.xcd_queues) HIP_TRY(hipMemsetAsync(b.xcd_cursors, 0, 16 * ((size_t)nseg + 1) * sizeof(uint32_t), l.main));
-        k_gen<<<sgrid, BLOCK, 0, l.main>>>(c->frame, *p, seeds, j, npaths, b, l.passcolor);
+        k_gen<<<sgrid, BLOCK, 0, l.main>>>(fr, *p, seeds, j, npaths, b, l.passcolor);
         if (nseg && (r = trace(0, -1))) return r;
         for (uint32_t seg = 0; seg < nseg; seg++) {
-            k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, c->frame, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
+            k_shade<false><<<sgrid, BLOCK, 0, l.main>>>(sc, fr, *p, seeds, b, (int)seg, (int)nseg, j, npaths, l.passcolor, c->d_counters);
             // the Sun-shadow queries of this segment travel with the closest-hit queries of the next one
             const int next_c = seg + 1 < nseg ? (int)seg + 1 : -1, sh = p->sunEnabled == 1 ? (int)seg : -1;
             if ((next_c >= 0 || sh >= 0) && (r = trace(next_c, sh))) return r;
@@ -716,6 +785,7 @@ int launch_run(gpuart_hip_ctx *c, size_t first, size_t count) {
     k_accumulate<<<dim3((unsigned)((c->plan.tile_pixels + 255) / 256)), 256, 0, c->stream>>>(c->d_accum, l.passcolor, c->plan.tile_pixels, b.batch);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(l.ev_free, c->stream));
+    if (gathers && (r = sort_tile_order(c, l))) return r;
     l.used = true;
     return 0;
 }
@@ -1403,6 +1473,57 @@ __global__ void k_test_stall(unsigned long long ticks, unsigned long long *sink)
     if (sink && threadIdx.x == 0) *sink = n;
 }
 }  // namespace
+int gpuart_hip_test_tile_order(gpuart_hip_ctx *c, const uint32_t *order, size_t n) {
+    if (!c || !c->frame.W) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = gpuart_hip_flush(c);
+    if (r || (r = drain(c))) return r;
+    if (!order) { c->frame.tile_order = nullptr; c->order_from_hook = false; c->order_cur = -1; c->order_sorting = false; c->order_stale = true; return 0; }
+    const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
+    if (n != tiles) return fail(GPUART_HIP_ERR_ARG, "the order must name every 8x8 block of the tile once");
+    std::vector<bool> seen(tiles, false);
+    for (size_t k = 0; k < n; k++) {
+        if (order[k] >= tiles || seen[order[k]]) return fail(GPUART_HIP_ERR_ARG, "the order must name every 8x8 block of the tile once");
+        seen[order[k]] = true;
+    }
+    if (!c->d_tile_order[0]) HIP_TRY(hipMalloc(&c->d_tile_order[0], tiles * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(c->d_tile_order[0], order, tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->frame.tile_order = c->d_tile_order[0];
+    c->order_from_hook = true; c->order_sorting = false;
+    return 0;
+}
+int gpuart_hip_test_current_tile_order(gpuart_hip_ctx *c, uint32_t *order, size_t n) {
+    if (!c || !c->frame.W) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = gpuart_hip_flush(c);
+    if (r || (r = drain(c))) return r;
+    if (c->order_sorting) {  // drained: the sort has finished
+        c->order_cur = c->order_next;
+        c->order_sorting = false;
+    }
+    const uint32_t *cur = c->order_from_hook ? c->frame.tile_order : c->order_cur >= 0 ? c->d_tile_order[c->order_cur] : nullptr;
+    if (!cur) return 0;
+    const size_t tiles = (size_t)((c->frame.tw + 7) / 8) * ((c->frame.th + 7) / 8);
+    if (!order || n != tiles) return fail(GPUART_HIP_ERR_ARG, "room for one entry per 8x8 block of the tile, please");
+    HIP_TRY(hipMemcpy(order, cur, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 1;
+}
+int gpuart_hip_test_sort_tiles(gpuart_hip_ctx *c, const uint32_t *cost, size_t n, uint32_t *order) {
+    if (!c || !cost || !order || n == 0 || n > 0x04000000u) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * n * sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(d, cost, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        k_tile_order<<<1, TO_THREADS, 0, c->stream>>>(d, d + n, (uint32_t)n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(order, d + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    return 0;
+}
 int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
     if (!c || ms > 5000) return fail(GPUART_HIP_ERR_ARG, "bad argument (at most 5000 ms)");
     HIP_TRY(hipSetDevice(c->device));

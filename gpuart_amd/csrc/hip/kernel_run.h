@@ -217,6 +217,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
                     }
                     F3 rstart = r.o, rdir = r.d;
                     if (COUNT) segments++;
+                    tile_cost_add(f, b, s);
                     const float4 seed = seeds.seed[slot_pass(b, s)];
                     ShadeResult sr = path_shade(sc, P, seed, seg, r, __uint_as_float(h.x), h.y, rstart, rdir, cw, pathColor);
                     if (sr.broke) {

@@ -84,9 +84,65 @@ GD_FN void flush_counters(const WorkCounters &wc, uint32_t segments, unsigned lo
 GD_FN bool slot_pixel(const Frame &f, uint32_t slot, uint32_t &lx, uint32_t &ly) {
     uint32_t tiles_x = (f.tw + 7) / 8;
     uint32_t t = slot >> 6, w = slot & 63;
+    if (f.tile_order) t = f.tile_order[t];
     lx = (t % tiles_x) * 8 + (w & 7);
     ly = (t / tiles_x) * 8 + (w >> 3);
     return lx < f.tw && ly < f.th;
+}
+
+/// A run that gathers the cost of the tile's 8x8 blocks (Frame::tile_cost, wave-uniform): one count per shaded path segment.
+GD_FN void tile_cost_add(const Frame &f, const PathBuffers &b, uint32_t slot) {
+    if (f.tile_cost) {
+        uint32_t t = slot_pixel_slot(b, slot) >> 6;
+        if (f.tile_order) t = f.tile_order[t];
+        atomicAdd(&f.tile_cost[t], 1u);
+    }
+}
+
+/// The birth order of the paths of the runs to come: the tile's 8x8 pixel blocks sorted by the cost the last gathering run counted
+/// for them, most expensive class first, row-major within a class (neighbouring blocks stay neighbours: they visit the same part of
+/// the tree). Why: a run ends when its LAST path ends, and a path is a chain of up to five dependent closest-hit queries — born
+/// last, a long path runs on with the machine nearly empty; born first, it overlaps with everything else, and the run drains on the
+/// one-segment paths of the sky (longest-processing-time-first). No pixel's value depends on the order. One workgroup; counts are
+/// quantised to TO_CLASSES classes of the largest count, sorted by counting (stable), and zeroed for the next gathering run.
+#define TO_THREADS 512
+#define TO_CLASSES 24
+__global__ void __launch_bounds__(TO_THREADS) k_tile_order(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t tiles) {
+    __shared__ uint32_t cnt[TO_CLASSES][TO_THREADS];
+    __shared__ uint32_t red[TO_THREADS];
+    __shared__ uint32_t class_base[TO_CLASSES];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (tiles + TO_THREADS - 1) / TO_THREADS;  // thread `tid` owns the blocks [lo, hi): in order, so that the sort is stable
+    const uint32_t lo = min(tid * per, tiles), hi = min(lo + per, tiles);
+    uint32_t mx = 0;
+    for (uint32_t i = lo; i < hi; i++) mx = max(mx, cost[i]);
+    red[tid] = mx;
+    __syncthreads();
+    for (uint32_t s = TO_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = max(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    auto cls = [mx](uint32_t v) { return (uint32_t)(TO_CLASSES - 1) - (uint32_t)(((unsigned long long)v * TO_CLASSES) / ((unsigned long long)mx + 1)); };  // 0: the most expensive
+    for (uint32_t c = 0; c < TO_CLASSES; c++) cnt[c][tid] = 0;
+    for (uint32_t i = lo; i < hi; i++) cnt[cls(cost[i])][tid]++;
+    __syncthreads();
+    if (tid < TO_CLASSES) {  // within a class: the blocks of thread 0, then thread 1, ...
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < TO_THREADS; k++) { const uint32_t v = cnt[tid][k]; cnt[tid][k] = run; run += v; }
+        class_base[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t c = 0; c < TO_CLASSES; c++) { const uint32_t v = class_base[c]; class_base[c] = run; run += v; }
+    }
+    __syncthreads();
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t c = cls(cost[i]);
+        order[class_base[c] + cnt[c][tid]++] = i;
+        cost[i] = 0;
+    }
 }
 
 /// The traversal stack of this lane: its column of the wave's LDS ring, its column of the launch's spill area
@@ -422,6 +478,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
         uint32_t slot = e < n ? queue[e] : SLOT_INVALID;
         bool go_on = false, shadow = false;
         if (slot != SLOT_INVALID) {
+            tile_cost_add(f, b, slot);
             Ray r; r.o = xyz(b.ray_o[slot]); r.d = xyz(b.ray_d[slot]);
             uint2 h = b.hit[slot];
             F3 cw = f3(1, 1, 1), pathColor = f3(0, 0, 0);  // path_tracing.glsl:156-157

@@ -251,6 +251,21 @@ int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flag
  * exactly once, every rank ready — else the error code it would return on every rank (gpuart_hip_last_error says why). */
 int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *status, int n, int which, int root);
 
+/* The order in which the paths of a pass are BORN: path slots [64 k, 64 k + 64) hold the 8x8 pixel block order[k] of the context's
+ * tile (blocks numbered row-major, ceil(tw / 8) per row; `n` = their number). No pixel's value depends on it — a path's random
+ * numbers come from hit positions and the pass's seed (path_tracing.glsl:164-165, 220) — which the parity tests check with
+ * arbitrary permutations. order == NULL: back to row-major. Dropped when the tile or frame size changes. */
+int gpuart_hip_test_tile_order(gpuart_hip_ctx *ctx, const uint32_t *order, size_t n);
+
+/* The library's own choice of that order (runs of one pass through the persistent kernel, GPUART_HIP_TILE_ORDER=0 turns it off): the
+ * first such run after a change of tile, camera or scene counts the shaded path segments per block, a device sort behind it puts the
+ * blocks into classes of that count, most expensive class first and row-major within a class, and the runs that follow are born in
+ * that order. This hook runs the sort alone: `cost[n]` -> `order[n]` (a permutation of 0 .. n-1). */
+int gpuart_hip_test_sort_tiles(gpuart_hip_ctx *ctx, const uint32_t *cost, size_t n, uint32_t *order);
+/* The order the next run of one pass would be born in (after everything launched so far has finished): 1 and `order[n]` filled, or
+ * 0 if there is none yet (row-major); < 0 on error. */
+int gpuart_hip_test_current_tile_order(gpuart_hip_ctx *ctx, uint32_t *order, size_t n);
+
 /* Keeps the context's primary stream busy for `ms` milliseconds (one idle-spinning wave that ends by itself; at most 5000):
  * what a peer that has not arrived looks like to the bounded waits of gpuart_hip_gather / gpuart_hip_wait, on one GPU. */
 int gpuart_hip_test_stall(gpuart_hip_ctx *ctx, uint32_t ms);

@@ -394,6 +394,85 @@ def test_frames_vs_reference_goldens(B, be, O, name):
         check_frame(be.read(1), g["pt_3paths"], "PT 3 paths/pass")
 
 
+def test_birth_order_of_the_paths_changes_no_pixel(B, O):
+    """Which path slot holds which pixel is a table (Frame::tile_order: a permutation of the tile's 8x8 pixel blocks): a path's random
+    numbers come from hit positions and the pass's seed (path_tracing.glsl:164-165, 220), so the reference's frames must come out for
+    ANY permutation — row-major, reversed, random, and the library's own (single-pass runs of the persistent kernel: the first counts
+    the shaded segments per block, a device sort orders the blocks by them, the following runs are born most expensive first). Full
+    frames against the reference's goldens, a ragged tile against the crop, direct lighting, k_run and the launch pipeline, several
+    paths per pass; every pass flushed alone so that runs of one pass happen."""
+    b = B.Backend(0)
+    try:
+        for name in ("frames_scene_d_seg5", "frames_scene_pc_seg5"):
+            g = golden(name)
+            W, H = int(g["W"]), int(g["H"])
+            npass = int(g["npasses"]) if "npasses" in g else 2
+            b.resize(W, H); b.upload_bvh(O.build_bvh(scene(str(g["scene"])))[0]); b.set_camera(g["cam"])
+            P = to_params(B, frame_golden_params(O, g)())
+            rng = np.random.RandomState(11)
+            for tile in (None, (5, 3, 99, 61)):
+                if tile:
+                    b.set_tile(*tile)
+                    x0, y0, tw, th = tile
+                else:
+                    x0, y0, tw, th = 0, 0, W, H
+                crop = lambda a: a[y0:y0 + th, x0:x0 + tw]
+                tiles = ((tw + 7) // 8) * ((th + 7) // 8)
+                for label, order in (("row-major", np.arange(tiles)), ("reversed", np.arange(tiles)[::-1]), ("random", rng.permutation(tiles)), ("own", None)):
+                    b.test_tile_order(order)
+                    for mode in (0, 3, 5):
+                        what = "%s, tile %s, %s order, mode %d: " % (name, tile, label, mode)
+                        b.set_mode(mode)
+                        b.render_direct(P)
+                        check_frame(b.read(0), crop(g["direct"]), what + "direct")
+                        b.pt_reset()
+                        for k in range(npass):
+                            b.pt_pass(P, g["seeds"][k], 1)
+                            b.flush()
+                            if k == 0:
+                                check_frame(b.read(1), crop(g["pt_pass1"]), what + "first pass")
+                        check_frame(b.read(1), crop(g["pt_acc"]), what + "%d passes" % npass)
+                        b.pt_reset()
+                        b.pt_pass(P, g["seeds"][0], 3)
+                        check_frame(b.read(1), crop(g["pt_3paths"]), what + "3 paths per pass")
+                    cur = b.test_current_tile_order()
+                    if order is not None:
+                        assert np.array_equal(cur, order.astype(np.uint32))
+                    else:
+                        # the library's own: in use after the single-pass runs above, a permutation, and not the trivial one on a frame
+                        # whose blocks differ in cost (sky / floor / mesh)
+                        assert cur is not None and np.array_equal(np.sort(cur), np.arange(tiles)), what
+                        assert not np.array_equal(cur, np.arange(tiles)), what
+            b.set_mode(0)
+        # bad tables are refused
+        with pytest.raises(B.HipError):
+            b.test_tile_order(np.zeros(tiles, np.uint32))
+        with pytest.raises(B.HipError):
+            b.test_tile_order(np.arange(tiles + 1))
+        # a change of the tile drops the table
+        b.test_tile_order(np.arange(tiles)[::-1])
+        b.set_tile(0, 0, 64, 40)
+        assert b.test_current_tile_order() is None
+    finally:
+        b.close()
+
+
+def test_blocks_are_sorted_by_cost_class_most_expensive_first(be):
+    """k_tile_order alone (gpuart_hip_test_sort_tiles): a permutation; classes of the largest count (24 of them) in descending order;
+    row-major within a class (stable) — neighbouring blocks stay neighbours; all-equal counts give the row-major order."""
+    rng = np.random.RandomState(5)
+    for n in (1, 7, 511, 512, 513, 144, 32400, 200001):
+        for kind in ("random", "few", "equal", "zero", "ramp"):
+            cost = {"random": rng.randint(0, 5000, n), "few": rng.choice([64, 128, 320], n), "equal": np.full(n, 77), "zero": np.zeros(n, np.int64),
+                    "ramp": np.arange(n)}[kind].astype(np.uint32)
+            order = be.test_sort_tiles(cost)
+            assert np.array_equal(np.sort(order), np.arange(n)), (n, kind)
+            mx = int(cost.max())
+            cls = 23 - (cost.astype(np.uint64) * 24 // (mx + 1)).astype(np.int64)
+            want = np.argsort(cls, kind="stable")
+            assert np.array_equal(order, want.astype(np.uint32)), (n, kind)
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("name", ["frames_box_seg5", "frames_scene_pc_seg5", "frames_scene_d_seg8", "frames_box_usph_fuzzy",
                                   "frames_box_usph_em", "frames_tree_near_seg5", "frames_scene_p_seg4"])
