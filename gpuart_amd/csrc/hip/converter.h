@@ -91,6 +91,14 @@ struct Converter {
     /// that agree with its two centres and radii. Hostile input (negative radii, NaN, a hand-made tree) fails this and keeps
     /// the reference's order throughout, like a tree with irregular boxes.
     bool disorderly = false;
+    /// Some box plane is a subnormal number (the device reads it as zero): the quick box answers (box_quick.h) are sized for planes
+    /// that are normal or zero, such a tree runs its six face tests every time.
+    bool subnormal = false;
+    static bool tiny(const Child &c) {
+        bool r = false;
+        for (int k = 0; k < 3; k++) r = r || std::fpclassify(c.bmin[k]) == FP_SUBNORMAL || std::fpclassify(c.bmax[k]) == FP_SUBNORMAL;
+        return r;
+    }
     static bool box_in_box(const float *cmin, const float *cmax, const float *bmin, const float *bmax) {
         bool ok = true;
         for (int k = 0; k < 3; k++) ok = ok && cmin[k] >= bmin[k] && cmax[k] <= bmax[k] && cmin[k] <= cmax[k];  // NaN fails
@@ -196,7 +204,7 @@ struct Converter {
 
     /// Pass 2 — the entries [from, to) of the table into the device arrays (disjoint writes: any number of threads).
     /// Returns whether one of the boxes written is irregular.
-    bool fill(size_t from, size_t to, bool &loose) {
+    bool fill(size_t from, size_t to, bool &loose, bool &sub) {
         bool irr = false;
         auto bad = [](const Child &c) {
             bool r = false;
@@ -222,6 +230,7 @@ struct Converter {
             } else {
                 const Child L = child_of(table[i + 1]), H = child_of(table[n.hi_index]);
                 irr = irr || bad(L) || bad(H);
+                sub = sub || tiny(L) || tiny(H);
                 loose = loose || !box_in_box(L.bmin, L.bmax, b, b + 4) || !box_in_box(H.bmin, H.bmax, b, b + 4);
                 float4 *r = recs.data() + 4 * (size_t)n.ref;
                 r[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], fbits(L.ref));
@@ -245,9 +254,10 @@ struct Converter {
         note(root);
         const size_t n = table.size();
         const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 16384));
-        std::vector<char> irr(parts, 0), loose(parts, 0);
+        std::vector<char> irr(parts, 0), loose(parts, 0), sub(parts, 0);
+        subnormal = tiny(root);
         std::vector<std::thread> pool;
-        auto work = [&](unsigned k) { bool l = false; irr[k] = fill(n * k / parts, n * (size_t)(k + 1) / parts, l) ? 1 : 0; loose[k] = l ? 1 : 0; };
+        auto work = [&](unsigned k) { bool l = false, t = false; irr[k] = fill(n * k / parts, n * (size_t)(k + 1) / parts, l, t) ? 1 : 0; loose[k] = l ? 1 : 0; sub[k] = t ? 1 : 0; };
         for (unsigned k = 1; k < parts; k++) {
             try { pool.emplace_back(work, k); } catch (const std::system_error &) { work(k); }
         }
@@ -255,6 +265,7 @@ struct Converter {
         for (auto &t : pool) t.join();
         for (char v : irr) irregular = irregular || v;
         for (char v : loose) disorderly = disorderly || v;
+        for (char v : sub) subnormal = subnormal || v;
         std::vector<NodeInfo>().swap(table);
         return true;
     }

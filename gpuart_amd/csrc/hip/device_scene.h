@@ -19,6 +19,17 @@
 #pragma once
 #include "device_math.h"
 
+// The quick box answer (box_quick.h: certainly the reference's, or withdrawn) on the device's own instructions: v_min / v_max drop a
+// NaN operand, v_med3 turns into min3 when it meets one, |x| is a source modifier, the fma is explicit.
+#define GQ_FN __device__ __forceinline__
+#define GQ_HOST_FN __host__ __device__ static inline
+GQ_FN float gq_min(float a, float b) { return fminf(a, b); }
+GQ_FN float gq_max(float a, float b) { return fmaxf(a, b); }
+GQ_FN float gq_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+GQ_FN float gq_fma(float a, float b, float c) { return fmaf(a, b, c); }
+GQ_FN float gq_abs(float a) { return fabsf(a); }
+#include "box_quick.h"
+
 namespace gd {
 
 enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
@@ -79,6 +90,9 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #ifndef GD_CERT_HITS
 #define GD_CERT_HITS 1
 #endif
+#ifndef GD_QUICK_BOXES
+#define GD_QUICK_BOXES 1   ///< fast-form box tests try the quick answer of box_quick.h first (0: always the six face tests; A/B builds)
+#endif
 #define GD_PRIM_LOOSE 0x40000000u  ///< in Trav::hit_prim during a NEAREST walk: a box on the winner's path is entered beyond the winner's parameter
 #define GD_PRIM_ADRIFT 0x20000000u ///< ... beyond the winner's parameter x BAND: the parameter and its boxes disagree by more than rounding
 #define GD_PRIM_FLAGS (GD_PRIM_LOOSE | GD_PRIM_ADRIFT)
@@ -89,6 +103,7 @@ struct Scene {
     float root_min[3], root_max[3];
     uint32_t root_ref;    ///< record index, or GD_REF_LEAF | first primitive
     uint32_t exact_boxes; ///< some box of the tree is irregular (min > max or NaN on an axis): every box test takes the comparison form
+    float box_slack;      ///< box_quick.h's slack constant for this tree (gq_slack_of_tree; +inf: every quick answer is withdrawn)
 };
 
 
@@ -335,6 +350,23 @@ GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos, bool 
     }
     return inside | hit;
 }
+
+/// The quick answer for one box (box_quick.h) on aabb_entry's own plane parameters; `cs` = gq_ray_slack of the ray. True: `hit` and
+/// `pos` are what aabb_entry returns (and the box is not odd). False: withdrawn — ask aabb_entry.
+GD_FN bool box_quick(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float cs, float &pos, bool &hit) {
+    const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
+    const float k0 = (bmin.x - r.o.x) * rdiv.x, k1 = (bmax.x - r.o.x) * rdiv.x;
+    const float k2 = (bmin.y - r.o.y) * rdiv.y, k3 = (bmax.y - r.o.y) * rdiv.y;
+    const float k4 = (bmin.z - r.o.z) * rdiv.z, k5 = (bmax.z - r.o.z) * rdiv.z;
+    return gq_box(inside, k0, k1, k2, k3, k4, k5, fabsf(rdiv.x), fabsf(rdiv.y), fabsf(rdiv.z), cs, pos, hit);
+}
+
+#ifdef GD_QUICK_CHECK
+// Diagnostic build (never the product): every fast-form box test of a step is ALSO run through the six face tests and the quick
+// answers that stand are compared with them. [0] boxes, [1] quick answers that stand, [2] steps, [3] steps that had to run the face
+// tests (a lane withdrew), [4] standing answers that differ from the face tests (must stay 0), [5] of them: marked odd by the face tests.
+__device__ unsigned long long g_quick_stats[8];
+#endif
 
 /// Running result of one query (the traversal state proper follows below).
 struct Trav {
@@ -678,6 +710,41 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     if (BOXES == GD_BOXES_EXACT || (BOXES == GD_BOXES_RUNTIME && sc.exact_boxes)) {  // trees with an irregular box (wild input) only
         hl = aabb_entry<true>(r, rdiv, xyz(q0), xyz(q1), el);
         hh = aabb_entry<true>(r, rdiv, xyz(q2), xyz(q3), eh);
+    } else if (GD_QUICK_BOXES && BOXES == GD_BOXES_FAST) {
+        // the quick answer first (box_quick.h): it stands for all but a few boxes in a million; the lanes where one of the two is
+        // withdrawn run the six face tests (a divergent region that the wave skips when no lane needs it)
+        const float cs = gq_ray_slack(sc.box_slack, r.d.x, r.d.y, r.d.z);
+        const bool sl = box_quick(r, rdiv, xyz(q0), xyz(q1), cs, el, hl);
+        const bool sh = box_quick(r, rdiv, xyz(q2), xyz(q3), cs, eh, hh);
+        bool ol = false, oh = false;
+#ifdef GD_QUICK_CHECK
+        {
+            float fl, fh; bool xl, xh;
+            const bool gl = aabb_entry<false, true>(r, rdiv, xyz(q0), xyz(q1), fl, &xl);
+            const bool gh = aabb_entry<false, true>(r, rdiv, xyz(q2), xyz(q3), fh, &xh);
+            const bool bad_l = sl & ((gl != hl) | (gl & (fl != el)) | xl), bad_h = sh & ((gh != hh) | (gh & (fh != eh)) | xh);
+            const unsigned long long act = __ballot(1), need = __ballot(!(sl & sh));
+            if (__ffsll((long long)act) - 1 == (int)(threadIdx.x & 63)) {
+                atomicAdd(&g_quick_stats[0], 2ull * __popcll(act));
+                atomicAdd(&g_quick_stats[2], 1ull);
+                if (need) atomicAdd(&g_quick_stats[3], 1ull);
+            }
+            atomicAdd(&g_quick_stats[1], (unsigned long long)sl + (unsigned long long)sh);
+            if (bad_l | bad_h) atomicAdd(&g_quick_stats[4], (unsigned long long)bad_l + (unsigned long long)bad_h);
+            if ((sl & xl) | (sh & xh)) atomicAdd(&g_quick_stats[5], 1ull);
+        }
+#endif
+        if (!(sl & sh)) {
+            // (the boxes are fetched again — an L1 hit, a few times per million boxes — so that the record's 14 registers are not
+            //  kept alive across the quick tests for this region's sake: k_trace has none to spare)
+            const float4 *again = rec;
+            asm volatile("" : "+v"(again));
+            const float4 p0 = again[0], p1 = again[1], p2 = again[2], p3 = again[3];
+            hl = aabb_entry<false, true>(r, rdiv, xyz(p0), xyz(p1), el, &ol);
+            hh = aabb_entry<false, true>(r, rdiv, xyz(p2), xyz(p3), eh, &oh);
+        }
+        // a box whose entry parameter is not its slab entry: this query's answer may hinge on the visiting order (trav_settle)
+        if (NEAREST && GD_CERT_ODD) t.second = (ordered & (ol | oh)) ? -__builtin_inff() : t.second;
     } else if (NEAREST && GD_CERT_ODD) {
         bool ol, oh;
         hl = aabb_entry<false, true>(r, rdiv, xyz(q0), xyz(q1), el, &ol);

@@ -128,6 +128,8 @@ struct gpuart_hip_ctx {
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
     bool chunk_from_env = false;  ///< GPUART_HIP_CHUNK was given: no per-launch choice of the chunk size
+    float box_slack = 0;          ///< box_quick.h's slack constant of the uploaded tree (+inf: quick box answers are never taken)
+    uint32_t quick_boxes = 1;     ///< GPUART_HIP_QUICK_BOXES (0: box_slack stays +inf — every box test runs its six face tests)
     uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box, or a box that does not bound what it holds (converter.h):
                                   ///< box tests take the comparison form and every walk keeps the reference's order
     uint32_t max_depth = 0;
@@ -281,6 +283,7 @@ Scene scene_of(const gpuart_hip_ctx *c) {
     memcpy(s.root_min, c->root_min, 12); memcpy(s.root_max, c->root_max, 12);
     s.root_ref = c->root_ref;
     s.exact_boxes = c->exact_boxes;
+    s.box_slack = c->box_slack;
     s.prims = c->d_prims;
     return s;
 }
@@ -403,6 +406,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.xcd_queues = env_u32("GPUART_HIP_XCD_QUEUES", 0, 0, 1);
     c->order_auto = env_u32("GPUART_HIP_TILE_ORDER", 1, 0, 1) != 0;
     c->nearest_min_prims = env_u32("GPUART_HIP_NEAREST_MIN_PRIMS", 1024, 0, 0x7fffffff);
+    c->quick_boxes = env_u32("GPUART_HIP_QUICK_BOXES", 1, 0, 1);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
     c->plan.lanes_total = (uint32_t)c->lanes.size();
@@ -508,6 +512,12 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
     c->root_ref = root.ref;
     c->exact_boxes = (cv.irregular || cv.disorderly) ? 1u : 0u;
+    {   // box_quick.h: its margins are sized by the largest plane coordinate of the tree — the root's, since every box was checked to
+        // lie inside its parent's — and its lemmas want planes that are normal numbers or zero
+        float pmax = 0;
+        for (int k = 0; k < 3; k++) pmax = std::max(pmax, std::max(std::fabs(root.bmin[k]), std::fabs(root.bmax[k])));
+        c->box_slack = (c->exact_boxes || cv.subnormal || !c->quick_boxes) ? __builtin_inff() : gq_slack_of_tree(pmax);
+    }
     c->type_mask = cv.type_mask;
     c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
@@ -1440,7 +1450,7 @@ int gpuart_hip_test_intersect(gpuart_hip_ctx *c, int ptype, const float *rs, con
 }
 int gpuart_hip_test_aabb(gpuart_hip_ctx *c, const float *rs, const float *rd, const float *bmin, const float *bmax, int n, float *out) {
     const float *ins[] = {rs, rd, bmin, bmax}; float *outs[] = {out};
-    return run_hook(c, n, ins, 4, outs, 1, [&](auto &i, auto &o) { k_test_aabb<<<GRID1(n)>>>(i[0], i[1], i[2], i[3], n, o[0]); });
+    return run_hook(c, n, ins, 4, outs, 1, [&](auto &i, auto &o) { k_test_aabb<<<GRID1(n)>>>(i[0], i[1], i[2], i[3], n, o[0], (int)c->quick_boxes); });
 }
 int gpuart_hip_test_traverse(gpuart_hip_ctx *c, const float *rs, const float *rd, const float us[4], int n, int any_hit,
                              float *out0, float *out1) {
@@ -1532,6 +1542,17 @@ int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
     return 0;
 }
 
+#ifdef GD_QUICK_CHECK
+/// diagnostic builds only: reads (and clears) the counters of the quick box answers checked against the six face tests (device_scene.h)
+int gpuart_hip_debug_quick_stats(gpuart_hip_ctx *c, unsigned long long *out) {
+    if (!c || !out) return GPUART_HIP_ERR_ARG;
+    static unsigned long long zero[8];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gd::g_quick_stats), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gd::g_quick_stats), zero, sizeof(zero)));
+    return 0;
+}
+#endif
 #ifdef GD_RUN_TIMELINE
 /// diagnostic builds only: the per-wave timeline of the last k_run launch (kernel_run.h), 24 words per wave
 int gpuart_hip_debug_run_timeline(gpuart_hip_ctx *c, unsigned long long *out, size_t waves) {

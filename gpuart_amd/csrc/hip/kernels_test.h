@@ -48,7 +48,7 @@ __global__ void k_test_intersect(const float4 *rs, const float4 *rd, const float
     if (pos > 0) { o0[i] = make_float4(pos, p.x, p.y, p.z); o1[i] = make_float4(nn.x, nn.y, nn.z, 0); }
     else { o0[i] = make_float4(pos, 0, 0, 0); o1[i] = make_float4(0, 0, 0, 0); }
 }
-__global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bmin, const float4 *bmax, int n, float4 *out) {
+__global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bmin, const float4 *bmax, int n, float4 *out, int quick) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r; r.o = xyz(rs[i]); r.d = xyz(rd[i]);
@@ -58,7 +58,17 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
     const float big = 3.4028234663852886e+38f;
     const bool regular = (lo.x <= hi.x) & (lo.y <= hi.y) & (lo.z <= hi.z) & (fabsf(lo.x) <= big) & (fabsf(lo.y) <= big) & (fabsf(lo.z) <= big) &
                          (fabsf(hi.x) <= big) & (fabsf(hi.y) <= big) & (fabsf(hi.z) <= big);
-    bool h = regular ? aabb_entry(r, rdiv, lo, hi, pos) : aabb_entry<true>(r, rdiv, lo, hi, pos);
+    bool h;
+    if (regular) {
+        // as trav_step_box tests a box of a regular tree: the quick answer (box_quick.h, the slack sized by this box's own planes —
+        // the tightest a tree could have), and the six face tests where it is withdrawn
+        const float pmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(hi.x))), fmaxf(fabsf(hi.y), fabsf(hi.z)));
+        auto tiny = [](float v) { const uint32_t b = __float_as_uint(v); return (b & 0x7f800000u) == 0 && (b & 0x007fffffu) != 0; };  // (a subnormal plane: converter.h)
+        const bool sub = tiny(lo.x) | tiny(lo.y) | tiny(lo.z) | tiny(hi.x) | tiny(hi.y) | tiny(hi.z);
+        const float cs = gq_ray_slack((GD_QUICK_BOXES && quick && !sub) ? gq_slack_of_tree(pmax) : __builtin_inff(), r.d.x, r.d.y, r.d.z);
+        if (!box_quick(r, rdiv, lo, hi, cs, pos, h)) h = aabb_entry(r, rdiv, lo, hi, pos);
+    } else
+        h = aabb_entry<true>(r, rdiv, lo, hi, pos);
     out[i] = make_float4(h ? 1.0f : 0.0f, h ? pos : 0.0f, 0, 0);
 }
 template <bool ANY, bool NEAREST = false>
