@@ -13,7 +13,7 @@
 //   near = min(k_lo, k_hi), far = max(k_lo, k_hi)   (the plane the ray meets first / last; fl(p - o) * r is monotone in p)
 //   A(k) = fl(o + fl(k * d))                        the coordinate the reference tests when a face of ANOTHER axis has parameter k
 //   u = 2^-24; arithmetic is round-to-nearest with denormals flushed (inputs and results), as the product and llvmpipe run.
-// Margins: M(k) = RHO * |k| + E_a,  E_a = cs * |r_a|,  RHO = 2^-20 (16 u),  cs = 2^-20 * Pmax + 2^-90, Pmax >= every |plane| of the tree.
+// Margins: M(k) = RHO * |k| + E_a,  E_a = cs * |r_a|,  RHO = 10 u,  cs = 4 u * Pmax + 2^-90, Pmax >= every |plane| of the tree.
 //
 // Lemma F (a face certainly FAILS its a-check).  Let r finite and != 0, |d| < 2^20, k any float.
 //   k <= near - M(near)  =>  A(k) lies strictly before the nearer plane:  for d > 0, A(k) < lo.
@@ -22,9 +22,11 @@
 //   k d (1 + e3) + f3 with |e| <= u and flush errors |f| <= 2^-126. Hence near * d = (lo - o)(1 + t), |t| <= 3.1 u, up to (|f1| + |f2| d),
 //   and with k <= near - D:  o + x <= lo + 4.2 u |lo - o| - D d (1 - u) + 2^-126 (2 + d) (1 + u).  A(k) = fl(o + x) < lo holds as soon as
 //   o + x <= pred(lo), and pred(lo) >= lo - 2 u |lo| - 2^-125 (flushing included). So D >= 4.3 u |near| + (2.1 u |lo| + 2^-124) |r| + 2^-125
-//   suffices; M(near) exceeds it: RHO / 2 = 8 u > 4.3 u, cs |r| / 2 >= (4 u Pmax + 2^-91) |r| and cs |r| / 2 >= 2^-91 * 2^-20 > 2^-124.
-//   (The halves that remain unused cover the roundings of the margin arithmetic itself, below.) An overflowing k * d is +-inf on the
-//   right side. The second line and d < 0 are the same computation mirrored.
+//   suffices. What the code subtracts covers it with the roundings of its own two instructions (x = fl(near - E), U = fl(x - RHO |x|),
+//   relative error u each): where |near| <= 8 E, U <= near - E (1 - 18 u) and the requirement is at most near - (0.55 + 35 u) E - 2^-125
+//   (2.1 u Pmax |r| = 0.525 E; 2^-124 |r| and 2^-125 vanish beside E >= 2^-90 * 2^-20); elsewhere |x| >= 7/8 |near| (1 - u), so
+//   U <= near - E - (0.875 RHO - 2.25 u) |near| = near - E - 6.5 u |near|.
+//   An overflowing k * d is +-inf on the right side. The second line and d < 0 are the same computation mirrored.
 // Lemma P (a face certainly PASSES its a-check).  near + M(near) <= k <= far - M(far)  =>  lo <= A(k) <= hi.
 //   Proof: as above without the term 2 u |lo|: real o + x >= lo, and rounding to nearest is monotone (lo is a float; a flushed
 //   result is 0, which lies on the right side of a bound of the other sign). No overflow: |k d| <= max(|near d|, |far d|) ~ |plane - o|.
@@ -46,8 +48,7 @@
 // Rays the lemmas exclude withdraw by themselves: d_a = 0 (r = inf: E_a = inf, the sum is inf), r_a = 0 or |d_a| >= 2^20 (the caller's
 // cs is NaN then: quick_slack), NaN or infinite origins and directions (NaN parameters; an axis that drops out of U / V can only
 // withdraw a MISS, and the sum withdraws a CLEAN HIT). Flat boxes on the entry axis withdraw (far_c - M < near_c).
-// Roundings of the margin arithmetic: near_a -+ E_a is one fma, grow / shrink one more (relative error u each); where |near_a| <= 2 E_a
-// the relative term 4.3 u |near_a| is below 9 u E_a, elsewhere |near_a -+ E_a| >= |near_a| / 2 and RHO / 2 covers it.
+// (shrink / grow are monotone, so they are applied once, after the reduction over the axes.)
 //
 // Checked: tools/quick_box_check.cpp (this very file on the CPU under FTZ / DAZ against the reference's comparison form: adversarial
 // rays through edges, corners, planes; flat, nested, huge and tiny boxes) and -DGD_QUICK_CHECK device builds (every product box
@@ -58,7 +59,7 @@
 #error "the includer defines GQ_FN (function attributes) and gq_min / gq_max / gq_med3 / gq_fma / gq_abs"
 #endif
 
-#define GQ_RHO 9.5367431640625e-07f  // 2^-20
+#define GQ_RHO 5.9604644775390625e-07f  // 10 u = 10 * 2^-24
 
 /// The slack constant of a tree whose box planes are all finite, normal-or-zero and at most `pmax` in magnitude; +inf (every
 /// answer withdrawn) otherwise. Host side (converter / upload) and checker.
@@ -67,7 +68,7 @@
 #endif
 GQ_HOST_FN float gq_slack_of_tree(float pmax) {
     if (!(pmax >= 0.0f) || !(pmax <= 1.0e30f)) return __builtin_inff();
-    return 9.5367431640625e-07f * pmax + 8.0779356694631609e-28f;  // 2^-20 * Pmax + 2^-90
+    return 2.384185791015625e-07f * pmax + 8.0779356694631609e-28f;  // 4 u * Pmax + 2^-90
 }
 
 /// Per ray (per step, three instructions): the tree's slack, NaN when a direction component is too large for the lemmas

@@ -870,7 +870,7 @@ GD_FN void thin_fetch(const Scene &sc, const Trav &t, uint32_t sub, ThinFetch &p
 /// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them), on the parts of the record the
 /// replicas hold in `pf` (thin_fetch). Precondition: DESCEND.
 template <int M, bool NEAREST = false>
-GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, bool ordered = true) {
+GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, float slack, bool ordered = true) {
     const float INF = __builtin_inff();
     float e;  // this lane's box: entry parameter, GD_ENTRY_MISS when not hit
     uint32_t ref_lo, ref_hi;
@@ -898,13 +898,18 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         const float4 bmin = pf.a, bmax = pf.b;
         float pos;
         bool hit;
-        if (NEAREST) {
-            bool odd_box;
+        bool odd_box = false;
+        if (GD_QUICK_BOXES) {  // a pair: each lane one whole box — the quick answer first, as in trav_step_box (`slack`: Scene::box_slack)
+            const float cs = gq_ray_slack(slack, rd.x, rd.y, rd.z);
+            if (!box_quick(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), cs, pos, hit)) hit = aabb_entry<false, true>(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos, &odd_box);
+        } else if (NEAREST)
             hit = aabb_entry<false, true>(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos, &odd_box);
+        else
+            hit = aabb_entry(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos);
+        if (NEAREST) {
             const uint32_t odd = odd_box ? 1u : 0u;
             if (ordered & ((odd | quad_u<GD_QUAD_PERM(1, 0, 3, 2)>(odd)) != 0)) t.second = -INF;
-        } else
-            hit = aabb_entry(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos);
+        }
         e = hit ? pos : GD_ENTRY_MISS;
         ref_lo = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmin.w));
         ref_hi = quad_u<GD_QUAD_PERM(0, 0, 2, 2)>(__float_as_uint(bmax.w));
@@ -935,7 +940,7 @@ template <int M, bool NEAREST = false>
 GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, bool ordered = true) {
     ThinFetch pf;
     thin_fetch<M>(sc, t, sub, pf);
-    trav_step_box_thin_on<M, NEAREST>(ro, rd, rdiv, t, st, sub, pf, ordered);
+    trav_step_box_thin_on<M, NEAREST>(ro, rd, rdiv, t, st, sub, pf, sc.box_slack, ordered);
 }
 
 /// The pending leaf of a ray carried by M replicas, then the pop. A leaf of one or two triangles is split between the halves

@@ -362,7 +362,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
 #if RUN_PIPE
                     if (t.state == TRAV_DESCEND) {
-                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
+                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, sc.box_slack, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
                         thin_fetch<W>(sc, t, sub, pf);
                         fresh = (t.state & 8) != 0;
                     }

@@ -166,6 +166,51 @@ def test_aabb_irregular_boxes(be):
     assert_bits(be.test_aabb(pad4(g["rs"]), pad4(g["rd"]), pad4(g["bmin"]), pad4(g["bmax"]))[:, :2], g["out"], "AABB, irregular boxes")
 
 
+def test_quick_box_answers_equal_the_six_face_tests(B, monkeypatch):
+    """csrc/hip/box_quick.h answers a box from its six plane parameters alone where that is provably the reference's result and is
+    withdrawn elsewhere. Two contexts — quick answers on (the default) and off (GPUART_HIP_QUICK_BOXES=0: every box through
+    IntersectsAABB's six face tests) — must agree on every ray of a set made to hurt: rays aimed at corners, edges and faces of the
+    box and a few ulps beside them, origins on box planes, flat boxes, dyadic coordinates (exact ties), tiny and zero direction
+    components, NaN / inf / huge numbers. (The CPU soak of the same source: tests/test_quick_box.py.)"""
+    rng = np.random.default_rng(20260404)
+    n = 1 << 20
+    f32 = np.float32
+    scale = rng.choice(np.array([1, 1, 5, 0.01, 100, 1e4], f32), (n, 1))
+    dy = rng.random((n, 1)) < 0.25
+    centre = np.where(dy, rng.integers(-16, 17, (n, 3)) * 0.125, rng.uniform(-1, 1, (n, 3))).astype(f32) * scale
+    ext = np.where(dy, rng.integers(0, 9, (n, 3)) * 0.125, rng.uniform(0, 1, (n, 3)) * rng.choice(np.array([0, 1e-6, 1e-3, 0.05, 1], f32), (n, 3))).astype(f32) * scale
+    lo, hi = (centre - ext).astype(f32), (centre + ext).astype(f32)
+    on = rng.integers(0, 4, (n, 3))  # target: on the lower plane, on the upper plane, between them, anywhere near
+    u = rng.random((n, 3)).astype(f32)
+    tgt = np.where(on == 0, lo, np.where(on == 1, hi, np.where(on == 2, lo + (hi - lo) * u, lo + (hi - lo) * (3 * u - 1)))).astype(f32)
+    nudge = rng.integers(-3, 4, (n, 3)) * (rng.random((n, 3)) < 0.3)
+    tgt = (tgt.view(np.int32) + nudge.astype(np.int32)).view(f32)
+    org = np.where(dy, rng.integers(-16, 17, (n, 3)) * 0.125 * scale, tgt + scale * rng.choice(np.array([1e-3, 0.1, 3, 50], f32), (n, 1)) * rng.uniform(-1, 1, (n, 3))).astype(f32)
+    plane = rng.random((n, 3)) < 0.05
+    org = np.where(plane, np.where(rng.random((n, 3)) < 0.5, lo, hi), org).astype(f32)
+    d = (tgt - org).astype(f32)
+    with np.errstate(all="ignore"):
+        d = np.where(dy, d, d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), f32(1e-30))).astype(f32)
+    small = rng.random((n, 3)) < 0.05
+    d = np.where(small, rng.choice(np.array([0.0, -0.0, 6.2e-8, -1e-12, 1e-30], f32), (n, 3)), d).astype(f32)
+    hostile = rng.random((n, 3)) < 0.01
+    special = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3e38, 1e-39, 2e6], f32)
+    org = np.where(hostile, rng.choice(special, (n, 3)), org).astype(f32)
+    d = np.where(np.roll(hostile, 1, axis=0), rng.choice(special, (n, 3)), d).astype(f32)
+    out = []
+    for quick in ("1", "0"):
+        monkeypatch.setenv("GPUART_HIP_QUICK_BOXES", quick)
+        b = B.Backend(0)
+        try:
+            out.append(b.test_aabb(pad4(org), pad4(d), pad4(lo), pad4(hi))[:, :2].copy())
+        finally:
+            b.close()
+    q, f = out
+    assert np.array_equal(q[:, 0], f[:, 0]), "hit / miss differs at %s" % np.flatnonzero(q[:, 0] != f[:, 0])[:8]
+    assert np.array_equal(q[:, 1], f[:, 1]), "entry parameter differs at %s" % np.flatnonzero(q[:, 1] != f[:, 1])[:8]  # (+0 == -0)
+    assert 0.2 < float(f[:, 0].mean()) < 0.9
+
+
 def test_wild_scene_with_a_box_hit_through_its_irregular_axis():
     """Wild case 42874 of tests/fuzz_parity.py (found by the round-2 soak; 1 of 14 500 cases): a disc with radius -inf leaves
     its leaf with the box x, z in [-inf, inf], y in [9.9e30, -9.9e30]; the reference enters it through the y planes (entry
@@ -1011,6 +1056,9 @@ def test_pass_grouping_never_changes_the_result(B, be, O, plan, npaths, mode):
     # the persistent run kernel (what mode 0 picks for this small sequence): tiny grid, eager refills, generic kernels
     {"GPUART_HIP_RUN_WAVES_PER_CU": "1", "GPUART_HIP_REFILL_LANES": "1", "GPUART_HIP_LEAN_KERNELS": "0", "GPUART_HIP_MAX_BATCH": "5"},
     {"GPUART_HIP_RUN_WAVES_PER_CU": "32", "GPUART_HIP_REFILL_LANES": "64", "GPUART_HIP_LEAF_LANES": "1", "GPUART_HIP_LANE_BUDGET_MB": "64"},
+    # every box test through its six face tests (no quick answers: csrc/hip/box_quick.h), both pipelines
+    {"GPUART_HIP_QUICK_BOXES": "0"},
+    {"GPUART_HIP_QUICK_BOXES": "0", "GPUART_HIP_SMALL_KPATHS": "0"},
 ])
 def test_scheduling_knobs_never_change_the_result(B, O, env, monkeypatch):
     """Memory budget, lanes in flight, run sizes, persistent-grid size, refill / leaf thresholds, kernel specialisation:
