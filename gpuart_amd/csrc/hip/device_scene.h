@@ -713,7 +713,7 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     } else if (GD_QUICK_BOXES && BOXES == GD_BOXES_FAST) {
         // the quick answer first (box_quick.h): it stands for all but a few boxes in a million; the lanes where one of the two is
         // withdrawn run the six face tests (a divergent region that the wave skips when no lane needs it)
-        const float cs = gq_ray_slack(sc.box_slack, r.d.x, r.d.y, r.d.z);
+        const float cs = gq_ray_slack(sc.box_slack, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
         const bool sl = box_quick(r, rdiv, xyz(q0), xyz(q1), cs, el, hl);
         const bool sh = box_quick(r, rdiv, xyz(q2), xyz(q3), cs, eh, hh);
         bool ol = false, oh = false;
@@ -900,7 +900,7 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         bool hit;
         bool odd_box = false;
         if (GD_QUICK_BOXES) {  // a pair: each lane one whole box — the quick answer first, as in trav_step_box (`slack`: Scene::box_slack)
-            const float cs = gq_ray_slack(slack, rd.x, rd.y, rd.z);
+            const float cs = gq_ray_slack(slack, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, rdiv.x, rdiv.y, rdiv.z);
             if (!box_quick(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), cs, pos, hit)) hit = aabb_entry<false, true>(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos, &odd_box);
         } else if (NEAREST)
             hit = aabb_entry<false, true>(Ray{ro, rd}, rdiv, xyz(bmin), xyz(bmax), pos, &odd_box);

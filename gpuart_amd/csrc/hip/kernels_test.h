@@ -65,7 +65,7 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
         const float pmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(hi.x))), fmaxf(fabsf(hi.y), fabsf(hi.z)));
         auto tiny = [](float v) { const uint32_t b = __float_as_uint(v); return (b & 0x7f800000u) == 0 && (b & 0x007fffffu) != 0; };  // (a subnormal plane: converter.h)
         const bool sub = tiny(lo.x) | tiny(lo.y) | tiny(lo.z) | tiny(hi.x) | tiny(hi.y) | tiny(hi.z);
-        const float cs = gq_ray_slack((GD_QUICK_BOXES && quick && !sub) ? gq_slack_of_tree(pmax) : __builtin_inff(), r.d.x, r.d.y, r.d.z);
+        const float cs = gq_ray_slack((GD_QUICK_BOXES && quick && !sub) ? gq_slack_of_tree(pmax) : __builtin_inff(), r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
         if (!box_quick(r, rdiv, lo, hi, cs, pos, h)) h = aabb_entry(r, rdiv, lo, hi, pos);
     } else
         h = aabb_entry<true>(r, rdiv, lo, hi, pos);

@@ -57,7 +57,7 @@ static bool ref_aabb(V3 o, V3 d, V3 rdiv, V3 lo, V3 hi, float &pos) {
 
 // ---- the quick answer exactly as device_scene.h assembles it ---------------------------------------------------------------
 static bool quick(V3 o, V3 d, V3 rdiv, V3 lo, V3 hi, float cs_tree, float &pos, bool &hit) {
-    const float cs = gq_ray_slack(cs_tree, d.x, d.y, d.z);
+    const float cs = gq_ray_slack(cs_tree, o.x, o.y, o.z, d.x, d.y, d.z, rdiv.x, rdiv.y, rdiv.z);
     const bool inside = (gq_med3(o.x, lo.x, hi.x) == o.x) & (gq_med3(o.y, lo.y, hi.y) == o.y) & (gq_med3(o.z, lo.z, hi.z) == o.z);
     const float k0 = (lo.x - o.x) * rdiv.x, k1 = (hi.x - o.x) * rdiv.x;
     const float k2 = (lo.y - o.y) * rdiv.y, k3 = (hi.y - o.y) * rdiv.y;

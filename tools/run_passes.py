@@ -15,12 +15,16 @@ W, H = 1920, 1080
 cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
 r = B.Renderer(W, H, cam)
 r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
-WORKLOAD = os.environ.get("WORKLOAD", "cfg3")  # cfg3 | dragon871k (the tree that leaves the L2s) | cfg2
+WORKLOAD = os.environ.get("WORKLOAD", "cfg3")  # cfg3 | dragon871k (the tree that leaves the L2s) | cfg2 | cluster | tree
 if WORKLOAD == "cfg2":
     cam = dict(S.DEFAULT_CAMERA); cam["dir"] = S.camera_dir(cam)
     r.set_camera(cam)
-r.set_primitives(B.make_prims(S.scene_d(660, 660) if WORKLOAD == "dragon871k" else S.scene_p() if WORKLOAD == "cfg2" else S.scene_d()))
-r.set_max_path_segments(4 if WORKLOAD == "cfg2" else 8)
+if WORKLOAD in ("cluster", "tree"):  # the reference's primitive-list scenes on their stand-ins, near cameras, depth 5 (as bench.py --workload)
+    cam = dict(S.NEAR_CAMERAS[WORKLOAD]); cam["dir"] = S.camera_dir(cam)
+    r.set_camera(cam)
+r.set_primitives(B.make_prims(S.scene_d(660, 660) if WORKLOAD == "dragon871k" else S.scene_p() if WORKLOAD == "cfg2" else
+                              S.cluster_scene() if WORKLOAD == "cluster" else S.tree_scene() if WORKLOAD == "tree" else S.scene_d()))
+r.set_max_path_segments(4 if WORKLOAD == "cfg2" else 5 if WORKLOAD in ("cluster", "tree") else 8)
 r.backend.set_mode(int(os.environ.get('GPUART_MODE', '0')))
 r.backend.set_timing(int(os.environ.get('GPUART_TIMING', '0')))
 for _ in range(REPS):
