@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(64) k_valu_select(float *out, int iters, unsig
 }
 
 // ---- the product's box test on registers ---------------------------------------------------------
+template <bool QUICK = false>  // QUICK: the quick answer of box_quick.h (what the product runs for all but a few boxes in a million) instead of the six face tests
 __global__ void __launch_bounds__(64) k_aabb(float *out, int iters, unsigned long long *cycles) {
     using namespace gd;
     Ray r;
@@ -115,7 +116,13 @@ __global__ void __launch_bounds__(64) k_aabb(float *out, int iters, unsigned lon
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
         float e;
-        bool h = aabb_entry(r, rdiv, bmin, bmax, e);
+        bool h;
+        if (QUICK) {
+            const float cs = gq_ray_slack(gq_slack_of_tree(2.0f), r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);  // (per step here: the ray is opaque per iteration)
+            const bool sure = box_quick(r, rdiv, bmin, bmax, cs, e, h);
+            acc += sure ? 0.0f : 3.0f;
+        } else
+            h = aabb_entry(r, rdiv, bmin, bmax, e);
         acc += h ? e : 1.0f;
         // keep the compiler from hoisting or simplifying any part of the test: every operand is opaque per iteration
         asm volatile("" : "+v"(bmin.x), "+v"(bmin.y), "+v"(bmin.z), "+v"(bmax.x), "+v"(bmax.y), "+v"(bmax.z), "+v"(acc));
@@ -316,7 +323,7 @@ __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, co
 //      2 x dwordx3, every lane its own L1-resident record), two aabb_entry tests on the fetched boxes. MODE 0: both, 1: fetch only
 //      (the boxes are not tested), 2: tests only (boxes from registers). If the hardware overlaps the two across the waves of a SIMD,
 //      MODE 0 costs max(1, 2); if it cannot, their sum.
-template <int MODE>
+template <int MODE, bool QUICK = false>
 __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
     using namespace gd;
     __shared__ float4 s_stage[256];
@@ -327,6 +334,7 @@ __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, ui
     r.o = f3(0.1f + threadIdx.x * 0.01f, -3.0f, 1.0f);
     r.d = f3(0.02f * threadIdx.x - 0.6f, 1.0f, -0.1f);
     const F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    const float quick_cs = gq_ray_slack(gq_slack_of_tree(2.0f), r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
     F3 lo0 = f3(-1, -1, 0), hi0 = f3(1, 1, 2), lo1 = f3(-2, -1, 0), hi1 = f3(0.5f, 1, 3);
     float acc = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -364,7 +372,13 @@ __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, ui
         }
         if (MODE != 1 && MODE != 4) {
             float e0, e1;
-            const bool h0 = aabb_entry(r, rdiv, lo0, hi0, e0), h1 = aabb_entry(r, rdiv, lo1, hi1, e1);
+            bool h0, h1;
+            if (QUICK) {  // the step as the product runs it since round 4: two quick answers (the ray's slack is computed where the ray changes, i.e. outside)
+                const bool s0 = box_quick(r, rdiv, lo0, hi0, quick_cs, e0, h0), s1 = box_quick(r, rdiv, lo1, hi1, quick_cs, e1, h1);
+                acc += (s0 & s1) ? 0.0f : 3.0f;
+            } else {
+                h0 = aabb_entry(r, rdiv, lo0, hi0, e0); h1 = aabb_entry(r, rdiv, lo1, hi1, e1);
+            }
             acc += (h0 ? e0 : 1.0f) + (h1 ? e1 : 2.0f);
             asm volatile("" : "+v"(lo0.x), "+v"(lo0.y), "+v"(lo0.z), "+v"(hi0.x), "+v"(hi0.y), "+v"(hi0.z), "+v"(acc));
             asm volatile("" : "+v"(lo1.x), "+v"(lo1.y), "+v"(lo1.z), "+v"(hi1.x), "+v"(hi1.y), "+v"(hi1.z));
@@ -450,7 +464,8 @@ int main(int argc, char **argv) {
               "4 chains x (cmp, med3, cmp, cndmask, mul, add): 24 VALU + 6 SALU per round");
     }
     for (int w : {1, 2, 4, 6, 8}) {
-        timed("aabb_entry_registers", w, (double)iters, "box-tests(x64 lanes)", [&](int n, float *o, unsigned long long *c) { k_aabb<<<n, 64>>>(o, iters, c); });
+        timed("aabb_entry_registers", w, (double)iters, "box-tests(x64 lanes)", [&](int n, float *o, unsigned long long *c) { k_aabb<false><<<n, 64>>>(o, iters, c); });
+        timed("box_quick_registers", w, (double)iters, "box-tests(x64 lanes)", [&](int n, float *o, unsigned long long *c) { k_aabb<true><<<n, 64>>>(o, iters, c); });
     }
     // gather: arrays of 2^k records of 64 B
     for (uint32_t log2n : {8u, 16u, 20u}) {  // 16 KB (L1), 512 KB (L2), 4 MB (one L2), 64 MB (Infinity Cache), 512 MB (HBM)
@@ -527,10 +542,12 @@ int main(int argc, char **argv) {
             for (int w : {2, 4, 6, 8}) {
                 if (log2rec != 8u && w != 6) continue;
                 timed(nm("step_fetch_and_2_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<0><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed(nm("step_fetch_and_2_quick_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<0, true><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed(nm("step_fetch_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<1><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed(nm("step_coop_fetch_and_2_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<3><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed(nm("step_coop_fetch_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<4><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed("step_2_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed("step_2_quick_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2, true><<<n, 64>>>(recs, m, 1024, o, c); });
             }
         }
         CHECK(hipFree(recs));
