@@ -265,12 +265,12 @@ def main():
         c = be.counters(reset=True)
         be.set_mode(0)
         return [c.rays, c.nodes, c.prim_tests[0], c.prim_tests[1], c.prim_tests[2], c.prim_tests[3], c.segments,
-                c.algorithmic_bytes() + 32 * W * th * K, c.rewalks]
+                c.algorithmic_bytes() + 32 * W * th * K, c.rewalks, c.box_steps]
 
     counts = torch.tensor(count(1) + count(4), dtype=torch.float64, device=xdev)
     if dist is not None:
         dist.all_reduce(counts)
-    ref, exe = counts[:9].tolist(), counts[9:].tolist()
+    ref, exe = counts[:10].tolist(), counts[10:].tolist()
     rays, nodes, segments, alg_bytes = ref[0], ref[1], ref[6], ref[7]
 
     # ---- warm-up (untimed), then EXACTLY K timed passes ----
@@ -465,7 +465,7 @@ def main():
     else:
         source = "not collected (%s)" % ("--no-profile" if args.no_profile else "N > 1: one GPU's counters would not describe the job")
     roof = BL.assemble_roofline(ms_step, passes_profiled, prof, trace,
-                                executed={"nodes": exe[1] / K, "algorithmic_bytes": exe[7] / K},
+                                executed={"nodes": exe[1] / K, "steps": exe[9] / K, "algorithmic_bytes": exe[7] / K},
                                 reference={"nodes": nodes / K, "algorithmic_bytes": alg_bytes / K},
                                 kernel_events=(kernel_ms, launches, elapsed_all))
     roof["source"] = source

@@ -98,7 +98,8 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
                          K passes, repeated — and nothing else)
       prof             : {set tag: (totals, per family)} from read_counters, or None
       trace            : {family: (launches, summed ms)} of an un-instrumented --kernel-trace child, or None
-      executed / reference : dicts with nodes, algorithmic_bytes per pass (device counters of the fast mode / of the reference's work)
+      executed / reference : dicts with nodes (box tests), algorithmic_bytes per pass (device counters of the fast mode / of the reference's
+                         work); executed also steps (interior-node visits = record fetches)
       kernel_events    : (summed ms, launches, timed seconds) of the dominant kernel's launches measured live with HIP events
     Every fraction is achieved / peak of the SAME quantity over the SAME passes; None where a counter is missing."""
     s = ms_per_step * 1e-3
@@ -111,6 +112,9 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
                           "wave64 VALU instruction x 64 lanes. = valu_issue.frac x valu_issue.lane_util. The path is branchy scalar fp32 per ray "
                           "on a cache-resident tree: neither HBM nor MFMA is its roof (hbm.* and the algorithmic bytes are kept beside it, "
                           "SURVEY.md 8(d)); `kernels` and `%s_wave_states` say where the rest of the slots go" % dominant,
+            "frac_note": "a share of lane SLOTS spent on instructions, not a figure of merit: it fell from 0.34 to 0.26 when the box test went from "
+                         "~100 to ~50 instructions for the same boxes (quick box answers, csrc/hip/box_quick.h: same rays, same node visits, 11 % less "
+                         "time). Compare builds by ms_per_step; what the step lacks to its micro-benchmarked rate is node_visits.frac",
             "kernel": dominant + " (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
             "kernel_avg_ms": _r(ev_ms / max(1, ev_n), 5), "kernel_launches": ev_n,
             "kernel_concurrency": _r(ev_ms / (ev_span * 1e3), 3) if ev_span else None,
@@ -122,10 +126,15 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
             "l1_accesses": {"peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "achieved": None, "frac": None,
                             "definition": "TCP_TOTAL_CACHE_ACCESSES_sum of every kernel of a pass / ms_per_step against the highest rate tools/ubench "
                                           "reaches on the box with the product's node-fetch shape (one access per cycle and CU: 614.4)"},
-            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G node visits/s (lane level)",
-                            "achieved": _r(executed["nodes"] / s / 1e9, 2), "frac": _r(executed["nodes"] / s / 1e9 / STEP_PEAK_GVISITS),
-                            "definition": "box tests the fast mode executes (device counters; both children of every record it visits) / ms_per_step, "
-                                          "against 64 x the rate of tools/ubench's register-resident traversal step (own peak: a second opinion)"},
+            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G record visits/s (lane level: one lane fetching one 64-byte record and testing its two boxes)",
+                            "achieved": _r(executed["steps"] / s / 1e9, 2), "frac": _r(executed["steps"] / s / 1e9 / STEP_PEAK_GVISITS),
+                            "box_tests_per_s": _r(executed["nodes"] / s / 1e9, 2),
+                            "definition": "interior-node visits the fast mode executes (device counter box_steps: one record fetch + two box tests each) / "
+                                          "ms_per_step, against 64 lanes x the rate of tools/ubench's traversal step with every lane on its own L1-resident "
+                                          "record at k_trace's occupancy (own peak: a second opinion). CORRECTED at the end of round 4: the lines of rounds "
+                                          "2-4 divided BOX TESTS (two per visit; still here as box_tests_per_s) by this peak in VISITS — their 0.87-0.90 "
+                                          "were 0.44-0.45. What the visit rate lacks to the peak: lanes idle in a wave's step (lane_util), leaf steps, "
+                                          "refills and waits (`*_wave_states`)"},
             "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "algorithmic_bytes_per_pass_reference": reference["algorithmic_bytes"],
                     "algorithmic_bytes_per_pass_executed": executed["algorithmic_bytes"],

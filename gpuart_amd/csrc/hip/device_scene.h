@@ -63,7 +63,7 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 //     claims to be entered beyond hits that lie inside it — by up to its whole depth; what the reference finds there depends on
 //     when its walk arrives;
 //   * a finished query that met an odd box, or whose winner is adrift of its boxes by more than the band, or whose winner is loose
-//     AND has a runner-up within the band, is walked again in the reference's order (a few queries per million: 2 of 4.7e6 per 1080p pass of cfg3) — trav_settle;
+//     AND has a runner-up within the band, is walked again in the reference's order (about ten queries per million: 55 of 4.7e6 per 1080p pass of cfg3) — trav_settle;
 //   * trees whose boxes do not bound their contents at all (hostile input: converter.h prim_in_box) never walk nearest-first.
 // Why this suffices: let (t*, p*) be the nearest-first result, R the reference's. If every hit primitive's boxes are entered no
 // later than its parameter x (1 + eps), with BAND >= (1 + eps)^2: R was tested by the nearest-first walk, so t_R >= t*; the

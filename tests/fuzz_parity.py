@@ -132,6 +132,18 @@ def main():
         bad += 0 if ok else 1
     for be in backends:
         be.close()
+    # a library built with -DGD_QUICK_CHECK (tools/ab_build.sh qcheck ..., GPUART_LIBDIR) has run every fast-form box test of these scenes
+    # both ways — the quick answer of csrc/hip/box_quick.h and the six face tests: a standing answer that differs counts as a difference
+    lib = B.hip_lib()
+    if hasattr(lib, "gpuart_hip_debug_quick_stats"):
+        be = B.Backend(0)
+        ev = np.zeros(8, np.uint64)
+        lib.gpuart_hip_debug_quick_stats.argtypes = [C.c_void_p, C.c_void_p]
+        be._chk(lib.gpuart_hip_debug_quick_stats(be.ctx, ev.ctypes.data_as(C.c_void_p)))
+        be.close()
+        print("quick box answers: %.4g boxes, %.4f %% stand, %.3f %% of the steps ran the face tests, %d standing answers differ from them"
+              % (ev[0], 100.0 * ev[1] / max(1, ev[0]), 100.0 * ev[3] / max(1, ev[2]), ev[4]))
+        bad += int(ev[4])
     print("fuzz: %d scenes, %d with differences" % (count, bad))
     return 1 if bad else 0
 

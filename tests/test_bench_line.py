@@ -75,7 +75,7 @@ def test_roofline_block_from_stubbed_counters(tmp_path):
     trace = BL.read_kernel_trace(str(tmp_path / "trace"))
     assert trace["k_trace"] == (2, 3.0 * passes) and trace["k_gen"][0] == 1
     ms = 0.8
-    roof = BL.assemble_roofline(ms, passes, prof, trace, executed={"nodes": 1.6e8, "algorithmic_bytes": 8.0e9},
+    roof = BL.assemble_roofline(ms, passes, prof, trace, executed={"nodes": 1.6e8, "steps": 0.79e8, "algorithmic_bytes": 8.0e9},
                                 reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1))
     # the contract's keys
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -97,7 +97,9 @@ def test_roofline_block_from_stubbed_counters(tmp_path):
     assert roof["hbm"]["algorithmic_rate_over_peak"] == pytest.approx(8.0e9 / 0.8e-3 / 8e12, abs=1e-3) and roof["hbm"]["algorithmic_rate_over_peak"] > 1
     assert roof["hbm"]["algorithmic_rate_over_l2_peak"] == pytest.approx(8.0e9 / 0.8e-3 / 34.5e12, abs=1e-3) and roof["hbm"]["algorithmic_rate_over_l2_peak"] < 1
     assert roof["l2"]["hit_rate"] == pytest.approx(0.7) and roof["l1_accesses"]["achieved"] == pytest.approx(3e8 / 0.8e-3 / 1e9)
-    assert roof["node_visits"]["achieved"] == pytest.approx(1.6e8 / 0.8e-3 / 1e9, abs=0.01)
+    assert roof["node_visits"]["achieved"] == pytest.approx(0.79e8 / 0.8e-3 / 1e9, abs=0.01)  # record visits, not box tests (two per visit)
+    assert roof["node_visits"]["box_tests_per_s"] == pytest.approx(1.6e8 / 0.8e-3 / 1e9, abs=0.01)
+    assert roof["node_visits"]["frac"] == pytest.approx(0.79e8 / 0.8e-3 / 1e9 / BL.STEP_PEAK_GVISITS, abs=0.001)
     # the dominant kernel's wave states, and one row per kernel family sorted by summed time
     assert roof["k_trace_wave_states"]["executing"] == pytest.approx(0.4) and roof["k_trace_wave_states"]["s_waitcnt"] == pytest.approx(0.45)
     assert roof["k_trace_wave_states"]["issue_wait"] == pytest.approx(0.15)
@@ -110,13 +112,13 @@ def test_roofline_block_from_stubbed_counters(tmp_path):
     # live HIP-event figures of the dominant kernel
     assert roof["kernel_avg_ms"] == pytest.approx(2.0) and roof["kernel_concurrency"] == pytest.approx(4.0)
     # a different number of profiled passes changes every per-pass figure: the denominator is the children's own pass count
-    half = BL.assemble_roofline(ms, passes // 2, prof, trace, executed={"nodes": 1.6e8, "algorithmic_bytes": 8.0e9},
+    half = BL.assemble_roofline(ms, passes // 2, prof, trace, executed={"nodes": 1.6e8, "steps": 0.79e8, "algorithmic_bytes": 8.0e9},
                                 reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1))
     assert half["valu_issue"]["instr_per_pass"] == pytest.approx(2 * 5.6e8) and half["traffic"] == pytest.approx(2 * traffic)
 
 
 def test_roofline_block_without_counters_keeps_the_contract_keys():
-    roof = BL.assemble_roofline(1.0, 0, None, None, executed={"nodes": 1e8, "algorithmic_bytes": 1e9}, reference={"nodes": 2e8, "algorithmic_bytes": 2e9},
+    roof = BL.assemble_roofline(1.0, 0, None, None, executed={"nodes": 1e8, "steps": 0.5e8, "algorithmic_bytes": 1e9}, reference={"nodes": 2e8, "algorithmic_bytes": 2e9},
                                 kernel_events=(0.0, 0, 0.0))
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof
