@@ -128,7 +128,7 @@ struct gpuart_hip_ctx {
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
     bool chunk_from_env = false;  ///< GPUART_HIP_CHUNK was given: no per-launch choice of the chunk size
-    float box_slack = 0;          ///< box_quick.h's slack constant of the uploaded tree (+inf: quick box answers are never taken)
+    float box_slack = __builtin_inff();  ///< box_quick.h's slack constant of the uploaded tree (+inf — also before any upload —: quick box answers are never taken)
     uint32_t quick_boxes = 1;     ///< GPUART_HIP_QUICK_BOXES (0: box_slack stays +inf — every box test runs its six face tests)
     uint32_t exact_boxes = 0;     ///< the uploaded tree holds an irregular box, or a box that does not bound what it holds (converter.h):
                                   ///< box tests take the comparison form and every walk keeps the reference's order
