@@ -58,10 +58,17 @@ def main():
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--camera", choices=["default", "bench", "cluster", "tree"], default=None, help="another camera than the workload's own")
+    ap.add_argument("--ref-face-tests", action="store_true", help="the reference-order renderer runs every box through its six face tests "
+                    "(GPUART_HIP_QUICK_BOXES=0 for its context): the fast mode's quick box answers (csrc/hip/box_quick.h) against IntersectsAABB "
+                    "itself, over whole frames")
     a = ap.parse_args()
     W, H = (int(x) for x in a.frame.split("x"))
     with tempfile.TemporaryDirectory() as tmp:
-        fast, ref = make(a.workload, W, H, a.mode, tmp, a.camera), make(a.workload, W, H, 1, tmp, a.camera)
+        fast = make(a.workload, W, H, a.mode, tmp, a.camera)
+        if a.ref_face_tests:
+            os.environ["GPUART_HIP_QUICK_BOXES"] = "0"  # read when the context is created
+        ref = make(a.workload, W, H, 1, tmp, a.camera)
+        os.environ.pop("GPUART_HIP_QUICK_BOXES", None)
         fast.render_direct(); ref.render_direct()
         d = int((fast.read_direct()[..., :3].view(np.uint32) != ref.read_direct()[..., :3].view(np.uint32)).any(-1).sum())
         print("%s %dx%d: direct lighting: %d differing pixels" % (a.workload, W, H, d), flush=True)
