@@ -17,7 +17,7 @@ VALU_PEAK_GINSTR = 1228.8       # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wav
 VALU_MEASURED_GINSTR = 1058.0   # the highest issue rate tools/ubench reaches on the box: independent 4-byte v_add_f32, 128 between two branches, 8 waves per
                                 # SIMD = 2.32 cycles (6 waves: 2.44; 8-byte v_fma_f32: 2.54-2.72; profiles/r02/ubench.txt)
 VALU_SAME_MIX_GINSTR = 846.0    # the six-face box test (aabb_entry) on registers (87 VALU + 17 SALU per test: selects, dependent chains) at k_trace's 6 waves per SIMD;
-                                # the quick answers that replaced it for all but a few boxes in a million (box_quick.h, ~50 VALU, few selects) issue no slower
+                                # the quick answers that replaced it for all but a few boxes in 100 000 (box_quick.h, ~50 VALU, few selects) issue no slower
 L1_PEAK_GACC = 1010.0           # the highest vector-L1 (TCP) cache-access rate tools/ubench reaches on the box with the product's own node fetch
                                 # (profiles/r02/l1_access_calibration.txt); one access per cycle and CU would be 614.4
 STEP_PEAK_GVISITS = 244.7       # 64 lanes x 3.824e9 wave-steps/s: tools/ubench k_step<0, quick>, the product's traversal step (record fetch + two quick box answers) with

@@ -711,7 +711,7 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
         hl = aabb_entry<true>(r, rdiv, xyz(q0), xyz(q1), el);
         hh = aabb_entry<true>(r, rdiv, xyz(q2), xyz(q3), eh);
     } else if (GD_QUICK_BOXES && BOXES == GD_BOXES_FAST) {
-        // the quick answer first (box_quick.h): it stands for all but a few boxes in a million; the lanes where one of the two is
+        // the quick answer first (box_quick.h): it stands for all but a few boxes in 100 000; the lanes where one of the two is
         // withdrawn run the six face tests (a divergent region that the wave skips when no lane needs it)
         const float cs = gq_ray_slack(sc.box_slack, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
         const bool sl = box_quick(r, rdiv, xyz(q0), xyz(q1), cs, el, hl);
@@ -735,7 +735,7 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
         }
 #endif
         if (!(sl & sh)) {
-            // (the boxes are fetched again — an L1 hit, a few times per million boxes — so that the record's 14 registers are not
+            // (the boxes are fetched again — an L1 hit, a few times per 100 000 boxes — so that the record's 14 registers are not
             //  kept alive across the quick tests for this region's sake: k_trace has none to spare)
             const float4 *again = rec;
             asm volatile("" : "+v"(again));

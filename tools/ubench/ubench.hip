@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) k_valu_select(float *out, int iters, unsig
 }
 
 // ---- the product's box test on registers ---------------------------------------------------------
-template <bool QUICK = false>  // QUICK: the quick answer of box_quick.h (what the product runs for all but a few boxes in a million) instead of the six face tests
+template <bool QUICK = false>  // QUICK: the quick answer of box_quick.h (what the product runs for all but a few boxes in 100 000) instead of the six face tests
 __global__ void __launch_bounds__(64) k_aabb(float *out, int iters, unsigned long long *cycles) {
     using namespace gd;
     Ray r;
