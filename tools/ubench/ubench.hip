@@ -319,6 +319,27 @@ __global__ void __launch_bounds__(64) k_node(const float4 *__restrict__ recs, co
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// ---- a pointer-free (heap-numbered) node array: W distinct 48-byte records in use, spread over 2^depth slots — what does the address
+//      translation of a sparse 26-GB array cost a gather that the caches see exactly as they see a dense one? (profiles/r04/step_sensitivity.txt)
+__global__ void __launch_bounds__(64) k_sparse(const char *__restrict__ base, uint32_t mask, uint32_t nslots, int iters, float *out, unsigned long long *cycles) {
+    uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    const uint32_t zero = g_zero;
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        const uint32_t r = idx & mask;                                        // which of the W records
+        const uint32_t slot = __umulhi(r * 2654435761u, nslots);              // where it lives (a fixed pseudo-random slot per record)
+        const float4 *p = (const float4 *)(base + (size_t)slot * 48);
+        float4 a = p[0], b = p[1], c = p[2];
+        asm volatile("" : "+v"(a.w), "+v"(b.w), "+v"(c.w));
+        acc += ((a.x + a.y) + (a.z + b.x)) + ((b.y + b.z) + (c.x + c.y)) + (c.z + c.w);
+        idx = idx * 1664525u + 1013904223u + ((__float_as_uint(a.w) + __float_as_uint(b.w)) & zero);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 // ---- do the node fetch and the box arithmetic overlap? One traversal step as the product runs it: fetch a record (2 x dwordx4 +
 //      2 x dwordx3, every lane its own L1-resident record), two aabb_entry tests on the fetched boxes. MODE 0: both, 1: fetch only
 //      (the boxes are not tested), 2: tests only (boxes from registers). If the hardware overlaps the two across the waves of a SIMD,
@@ -489,6 +510,21 @@ int main(int argc, char **argv) {
         }
         CHECK(hipFree(recs));
     }
+    }
+    if (getenv("UBENCH_SPARSE")) {  // UBENCH_SPARSE=1: only this part
+        struct Case { uint32_t log2w, log2slots; } cases[] = {{16, 16}, {16, 24}, {20, 20}, {20, 29}};
+        for (const Case &cs : cases) {
+            const size_t bytes = ((size_t)1 << cs.log2slots) * 48;
+            char *base;
+            if (hipMalloc(&base, bytes) != hipSuccess) { printf("sparse: no %zu MB\n", bytes >> 20); continue; }
+            CHECK(hipMemset(base, 0, bytes));
+            char name[96];
+            snprintf(name, sizeof name, "sparse48B_3x4_%uK_records_in_%zuMB", (1u << cs.log2w) >> 10, bytes >> 20);
+            for (int w : {2, 6})
+                timed(name, w, 1024.0, "wave-fetches", [&](int n, float *o, unsigned long long *c) { k_sparse<<<n, 64>>>(base, (1u << cs.log2w) - 1, 1u << cs.log2slots, 1024, o, c); });
+            CHECK(hipFree(base));
+        }
+        return 0;
     }
     for (uint32_t log2rec : {8u, 13u, 16u}) {  // 16 KB (vector L1), 512 KB, 4 MB (one XCD's L2)
         const size_t nrec = (size_t)1 << log2rec;
