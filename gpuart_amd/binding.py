@@ -206,6 +206,18 @@ def tree_class(quads):
     return dict(irregular=bool(flags.value & 1), disorderly=bool(flags.value & 2), type_mask=(flags.value >> 8) & 15)
 
 
+def tree_slack(quads):
+    """(slack constant the upload would give the tree for its quick box answers — inf: none —, a box plane is subnormal), without a device."""
+    L = hip_lib()
+    q = np.ascontiguousarray(quads, np.float32)
+    slack, flags = C.c_float(0), C.c_uint32(0)
+    for rc in (L.gpuart_hip_test_tree_slack(_p(q), C.c_size_t(q.size // 4), C.byref(slack)),
+               L.gpuart_hip_test_tree_class(_p(q), C.c_size_t(q.size // 4), C.byref(flags))):
+        if rc != 0:
+            raise HipError("gpuart_hip error %d: %s" % (rc, L.gpuart_hip_last_error().decode()))
+    return float(slack.value), bool(flags.value & 4)
+
+
 def comm_library():
     """Path of the RCCL library libgpuart_hip resolved its entry points from (dladdr of ncclCommInitRank)."""
     L = hip_lib()

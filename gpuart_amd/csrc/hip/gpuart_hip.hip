@@ -277,6 +277,16 @@ void update_uv(gpuart_hip_ctx *c) {
     plane_coef(w, h, 0, 0, 0, h, 1, 0, 1, k + 9);  // B.v
 }
 
+/// box_quick.h's slack constant for a converted tree: its margins are sized by the largest plane coordinate of the tree — the root's,
+/// since every box was checked to lie inside its parent's — and its lemmas want planes that are normal numbers or zero. +inf (no quick
+/// box answers) for a tree with irregular or non-bounding boxes or a subnormal plane.
+float tree_slack(const Converter &cv, const Converter::Child &root) {
+    if (cv.irregular || cv.disorderly || cv.subnormal) return __builtin_inff();
+    float pmax = 0;
+    for (int k = 0; k < 3; k++) pmax = std::max(pmax, std::max(std::fabs(root.bmin[k]), std::fabs(root.bmax[k])));
+    return gq_slack_of_tree(pmax);
+}
+
 Scene scene_of(const gpuart_hip_ctx *c) {
     Scene s;
     s.recs = c->d_recs;
@@ -512,12 +522,7 @@ int gpuart_hip_upload_bvh(gpuart_hip_ctx *c, const float *quads, size_t nquads) 
     memcpy(c->root_min, root.bmin, 12); memcpy(c->root_max, root.bmax, 12);
     c->root_ref = root.ref;
     c->exact_boxes = (cv.irregular || cv.disorderly) ? 1u : 0u;
-    {   // box_quick.h: its margins are sized by the largest plane coordinate of the tree — the root's, since every box was checked to
-        // lie inside its parent's — and its lemmas want planes that are normal numbers or zero
-        float pmax = 0;
-        for (int k = 0; k < 3; k++) pmax = std::max(pmax, std::max(std::fabs(root.bmin[k]), std::fabs(root.bmax[k])));
-        c->box_slack = (c->exact_boxes || cv.subnormal || !c->quick_boxes) ? __builtin_inff() : gq_slack_of_tree(pmax);
-    }
+    c->box_slack = c->quick_boxes ? tree_slack(cv, root) : __builtin_inff();
     c->type_mask = cv.type_mask;
     c->n_nodes = cv.num_nodes;
     c->n_prims = cv.prims.size() / 3;
@@ -1334,7 +1339,21 @@ int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flag
         cv.q = quads; cv.nq = nquads;
         Converter::Child root;
         if (!cv.convert(root, 1)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
-        *flags = (cv.irregular ? 1u : 0u) | (cv.disorderly ? 2u : 0u) | (cv.type_mask << 8);
+        *flags = (cv.irregular ? 1u : 0u) | (cv.disorderly ? 2u : 0u) | (cv.subnormal ? 4u : 0u) | (cv.type_mask << 8);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(GPUART_HIP_ERR_ARG, std::string("tree: ") + e.what());
+    }
+}
+
+int gpuart_hip_test_tree_slack(const float *quads, size_t nquads, float *slack) {
+    if (!quads || !nquads || !slack) return fail(GPUART_HIP_ERR_ARG, "bad argument");
+    try {
+        Converter cv;
+        cv.q = quads; cv.nq = nquads;
+        Converter::Child root;
+        if (!cv.convert(root, 1)) return fail(GPUART_HIP_ERR_ARG, "malformed compiled BVH: " + cv.err);
+        *slack = tree_slack(cv, root);
         return 0;
     } catch (const std::exception &e) {
         return fail(GPUART_HIP_ERR_ARG, std::string("tree: ") + e.what());

@@ -243,8 +243,15 @@ int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_op
  * bit 1: some box does not bound what it holds by the reference's own formulas (a child outside its parent, a primitive outside its
  *        leaf's box, a negative radius, cone constants that contradict its centres, coordinates beyond 2^20) — with either bit the
  *        tree is walked in the reference's order throughout; with neither the fast kernels visit the nearer child first;
+ * bit 2: some box plane is a subnormal number (no quick box answers: below);
  * bits 8-11: the primitive types present. GPUART_HIP_ERR_ARG for a malformed tree (gpuart_hip_last_error says why). */
 int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flags);
+
+/* The slack constant the upload assigns to a tree for the quick box answers of the BVH queries (csrc/hip/box_quick.h: the slab entry
+ * of a box, taken where margins prove it equal to the reference's six face tests — IntersectsAABB, shaders/bvh_intersection.glsl:229-354 —
+ * bit for bit): 4 * 2^-24 * (largest |plane coordinate| of the root's box) + 2^-90, or +inf — every box test runs its six face tests —
+ * for a tree with bit 0, 1 or 2 of gpuart_hip_test_tree_class set (and, on a context, with GPUART_HIP_QUICK_BOXES=0). Pure host code. */
+int gpuart_hip_test_tree_slack(const float *quads, size_t nquads, float *slack);
 
 /* The validation every rank of gpuart_hip_gather applies to the exchanged share table (pure host code): `shares[k]` and
  * `status[k]` (0: ready) as rank k announced them. 0 if the gather would go ahead — full-width rows, every frame row covered

@@ -309,6 +309,36 @@ def test_cone_constants_equal_reference_vec3_arithmetic():
                 assert (box.view(np.uint32) == exp[16:].view(np.uint32)).all(), "%s cone %d box: got %s expected %s" % (name, i, box, exp[16:])
 
 
+def test_uploader_sizes_the_quick_box_answers_per_tree():
+    """The BVH queries answer a box from its six plane parameters where margins prove that equal to the reference's six face tests
+    (csrc/hip/box_quick.h). The margins are sized per tree at upload: 4 * 2^-24 * the largest plane coordinate + 2^-90 for a tree whose
+    boxes are regular, nested and free of subnormal planes — and +inf, i.e. never a quick answer, for any other
+    (gpuart_hip_test_tree_slack shows the decision without a device). Every BASELINE scene must get a finite slack or the fast path is
+    silently lost."""
+    from gpuart_amd import binding as B
+    from gpuart_amd import synth_scenes as S
+    f32 = np.float32
+    for name, descs in (("box", S.box_scene()), ("scene_d", S.scene_d()), ("scene_p", S.scene_p()), ("tree", S.tree_scene()), ("lattice", S.lattice_scene())):
+        tree, _ = B.compile_bvh(descs)
+        slack, sub = B.tree_slack(tree)
+        pmax = f32(np.abs(tree[0:2, :3]).max())  # the root's box: every other box lies inside it
+        assert not sub and slack == float(f32(f32(2.0 ** -22) * pmax + f32(2.0 ** -90))), (name, slack, pmax)
+        assert 0 < slack < 1e-4, (name, slack)
+    floor = (S.DISC, [0, 0, 0, 0, 0, 1, 6])
+    inf = float("inf")
+    assert B.tree_slack(B.compile_bvh([floor, (S.SPHERE, [0, 0, 1, -0.5])])[0])[0] == inf                    # a box that does not bound its sphere
+    assert B.tree_slack(B.compile_bvh([(S.SPHERE, [0, 0, 1, -0.5])])[0])[0] == inf                           # an inverted box
+    assert B.tree_slack(B.compile_bvh([floor, (S.TRIANGLE, [0, 0, 0.5, 1, 0, 0.5, 0, 2.0e6, 0.5])])[0])[0] == inf
+    # a triangle whose lowest x is a subnormal number: regular, nested — and still no quick answers
+    tiny = B.compile_bvh([floor, (S.TRIANGLE, [1.0e-40, 0, 0.5, 1, 0, 0.5, 0.5, 1, 0.5]), (S.TRIANGLE, [3, 3, 0.5, 4, 3, 0.5, 3, 4, 0.5])])[0]
+    c = B.tree_class(tiny)
+    assert not c["irregular"] and not c["disorderly"]
+    assert B.tree_slack(tiny) == (inf, True)
+    # ... while the same scene with that coordinate at 0 takes them
+    zero = B.compile_bvh([floor, (S.TRIANGLE, [0.0, 0, 0.5, 1, 0, 0.5, 0.5, 1, 0.5]), (S.TRIANGLE, [3, 3, 0.5, 4, 3, 0.5, 3, 4, 0.5])])[0]
+    assert B.tree_slack(zero)[0] < 1e-5 and not B.tree_slack(zero)[1]
+
+
 def test_uploader_classifies_trees_for_the_visiting_order():
     """The fast kernels visit a node's nearer child first only where boxes bound what they hold ("Nearer child
     first, with a certificate"); gpuart_hip_upload_bvh decides per tree, and gpuart_hip_test_tree_class shows the decision without a
