@@ -15,9 +15,10 @@
 //   u = 2^-24; arithmetic is round-to-nearest with denormals flushed (inputs and results), as the product and llvmpipe run.
 // Margins: M(k) = RHO * |k| + E_a,  E_a = cs * |r_a|,  RHO = 10 u,  cs = 4 u * Pmax + 2^-90, Pmax >= every |plane| of the tree (<= 2^40);
 //          m(k) = RHO * |k| + TAU, TAU = 2^-50, where only Lemma P is needed (it has no term in Pmax).
-// Rays: gq_ray_slack hands out the tree's cs only to a ray with |o_a| < 2^40, 2^-60 < |d_a| < 2^20 (so 2^-20 < |r_a| < 2^60) and no
-// NaN — every camera, bounce and shadow ray of a sane scene; any other ray gets NaN and every answer for it is withdrawn (all
-// comparisons below are false). For the rays that remain every plane parameter is finite, |k| < 2^101, and never NaN.
+// Rays: gq_ray_slack hands out the tree's cs only to a ray with |o_a| < 2^40 that is 0 or at least 2^-60, 2^-60 < |d_a| < 2^20 (so
+// 2^-20 < |r_a| < 2^60) and no NaN — every camera, bounce and shadow ray of a sane scene; any other ray gets NaN and every answer for
+// it is withdrawn (all comparisons below are false, and the inside answer is gated by cs == cs). For the rays that remain every plane
+// parameter is finite, |k| < 2^101, and never NaN. Trees: every plane coordinate is 0 or at least 2^-60 in magnitude (else cs = +inf).
 //
 // Lemma F (a face certainly FAILS its a-check).  k any float.
 //   k <= near - M(near)  =>  A(k) lies strictly before the nearer plane:  for d > 0, A(k) < lo.
@@ -51,7 +52,10 @@
 //        near_a <= med3(near) <= U, and U can only reach med3(near) when it is attained at c (near_b - M_b < near_b <= med3 for
 //        b != c), so near_a <= near_c - M_c and its c-check fails (F); every farther face has far_a >= T. So the reference's running
 //        minimum ends at T: hit, entry parameter min(T, 1e19) like aabb_entry, and the box is not `odd` (T is its slab entry).
-//  INSIDE is the reference's own inclusive test (:245-250), unchanged.
+//  INSIDE (the reference's inclusive test, :245-250: lo <= o <= hi on every axis)  <=>  T <= 0 <= min_a far_a, for vetted rays and trees:
+//        p - o is 0 or at least 2^-84 in magnitude (both are 0 or at least 2^-60), so s = fl(p - o) has the sign of p - o and is not
+//        flushed; |s r| >= 2^-104 is not flushed either, so k = fl(s r) has the sign of s times the sign of r (and k = +-0 for s = 0).
+//        With r > 0: k_lo <= 0 <= k_hi <=> lo <= o <= hi, and k_lo = near, k_hi = far; with r < 0 the two swap. (+0 and -0 compare equal.)
 // (shrink / grow are monotone, so they are applied once, after the reduction over the axes.)
 //
 // Checked: tools/quick_box_check.cpp (this very file on the CPU under FTZ / DAZ against the reference's comparison form: adversarial
@@ -70,31 +74,41 @@
 #define GQ_TAU 8.8817841970012523e-16f  // 2^-50
 #endif
 
-/// The slack constant of a tree whose box planes are all finite, normal-or-zero and at most `pmax` <= 2^40 in magnitude; +inf (every
-/// answer withdrawn) otherwise. Host side (converter / upload) and checker.
+/// The slack constant of a tree whose box planes are all finite, 0 or at least 2^-60 in magnitude (gq_plane_ok) and at most
+/// `pmax` <= 2^40; +inf (every answer withdrawn) otherwise. Host side (converter / upload) and checker.
 #ifndef GQ_HOST_FN
 #define GQ_HOST_FN static inline
 #endif
+GQ_HOST_FN bool gq_plane_ok(float p) { return p == 0.0f || (p >= 8.6736173798840355e-19f || p <= -8.6736173798840355e-19f); }  // (false for NaN)
 GQ_HOST_FN float gq_slack_of_tree(float pmax) {
     if (!(pmax >= 0.0f) || !(pmax <= 1.099511627776e12f)) return __builtin_inff();
     return 2.384185791015625e-07f * pmax + 8.0779356694631609e-28f;  // 4 u * Pmax + 2^-90
 }
 
 /// Per ray (a pure function of the ray: the compiler computes it where the ray changes, not per step): the tree's slack for a ray
-/// the lemmas cover, NaN for any other — a component of the origin at or beyond 2^40, of the direction at or beyond 2^20 or within
-/// 2^-60 of zero (rdiv at or beyond 2^60, +-inf for 0), a NaN anywhere. rx, ry, rz: the caller's rdiv = 1 / d.
+/// the lemmas cover, NaN for any other — a component of the origin at or beyond 2^40 or within 2^-60 of zero without being zero, of
+/// the direction at or beyond 2^20 or within 2^-60 of zero (rdiv at or beyond 2^60, +-inf for 0), a NaN anywhere. rx, ry, rz: the
+/// caller's rdiv = 1 / d.
 GQ_FN float gq_ray_slack(float cs, float ox, float oy, float oz, float dx, float dy, float dz, float rx, float ry, float rz) {
     const float wd = gq_max(gq_max(gq_abs(dx), gq_abs(dy)), gq_abs(dz)) * 3.2451855365842673e+32f;  // * 2^108: inf from 2^20 on
     const float wr = gq_max(gq_max(gq_abs(rx), gq_abs(ry)), gq_abs(rz)) * 2.9514790517935283e+20f;  // * 2^68:  inf from 2^60 on
     const float wo = gq_max(gq_max(gq_abs(ox), gq_abs(oy)), gq_abs(oz)) * 3.0948500982134507e+26f;  // * 2^88:  inf from 2^40 on
     const float nn = ((dx + dy) + dz) + ((ox + oy) + oz);                                           // NaN if any of them is (max drops NaNs)
-    return gq_fma(nn, 0.0f, gq_fma((wd + wr) + wo, 0.0f, cs));                                      // 0 * inf = NaN
+    const float TINY = 8.6736173798840355e-19f;                                                     // 2^-60: an origin component below it that is not 0
+    const float tx = gq_abs(ox) < TINY ? gq_abs(ox) : 0.0f, ty = gq_abs(oy) < TINY ? gq_abs(oy) : 0.0f, tz = gq_abs(oz) < TINY ? gq_abs(oz) : 0.0f;
+    const float c = gq_fma(nn, 0.0f, gq_fma((wd + wr) + wo, 0.0f, cs));                            // 0 * inf = NaN
+#ifdef GQ_NO_TINY_ORIGIN_GUARD  // teeth test of tools/quick_box_check.cpp only: without this guard the inside answer must go wrong
+    (void)tx; (void)ty; (void)tz;
+    return c;
+#else
+    return (tx + ty) + tz > 0.0f ? __builtin_nanf("") : c;
+#endif
 }
 
-/// `inside`: the reference's inclusive origin test (the caller has it). k0..k5: the six plane parameters in aabb_entry's order
-/// (x lo, x hi, y lo, y hi, z lo, z hi). ax, ay, az = |rdiv|. cs: gq_ray_slack. Returns whether the answer stands; then `hit` and
-/// `pos` (-1 inside, else the entry parameter; 1e19 on a miss, like aabb_entry) are the reference's. Otherwise both are unspecified.
-GQ_FN bool gq_box(bool inside, float k0, float k1, float k2, float k3, float k4, float k5, float ax, float ay, float az, float cs, float &pos, bool &hit) {
+/// k0..k5: the six plane parameters in aabb_entry's order (x lo, x hi, y lo, y hi, z lo, z hi). ax, ay, az = |rdiv|. cs: gq_ray_slack.
+/// Returns whether the answer stands; then `hit` and `pos` (-1 inside, else the entry parameter; 1e19 on a miss, like aabb_entry) are
+/// the reference's. Otherwise both are unspecified.
+GQ_FN bool gq_box(float k0, float k1, float k2, float k3, float k4, float k5, float ax, float ay, float az, float cs, float &pos, bool &hit) {
     const float nx = gq_min(k0, k1), fx = gq_max(k0, k1);
     const float ny = gq_min(k2, k3), fy = gq_max(k2, k3);
     const float nz = gq_min(k4, k5), fz = gq_max(k4, k5);
@@ -108,6 +122,7 @@ GQ_FN bool gq_box(bool inside, float k0, float k1, float k2, float k3, float k4,
     V = gq_fma(GQ_RHO, gq_abs(V), V);
     const float NI = gq_fma(GQ_RHO, gq_abs(m2), m2);
     const float FI = gq_fma(-GQ_RHO, gq_abs(X), X);
+    const bool inside = (T <= 0.0f) & (X >= 0.0f) & (cs == cs);
     const bool miss = gq_max(U, 0.0f) >= V;
     const bool clean = (T >= 0.0f) & (NI <= T - GQ_TAU) & (T + GQ_TAU <= FI) & (m2 <= U);
     hit = inside | clean;

@@ -91,12 +91,13 @@ struct Converter {
     /// that agree with its two centres and radii. Hostile input (negative radii, NaN, a hand-made tree) fails this and keeps
     /// the reference's order throughout, like a tree with irregular boxes.
     bool disorderly = false;
-    /// Some box plane is a subnormal number (the device reads it as zero): the quick box answers (box_quick.h) are sized for planes
-    /// that are normal or zero, such a tree runs its six face tests every time.
+    /// Some box plane lies within 2^-60 of zero without being zero (a subnormal number, which the device reads as zero, included): the
+    /// quick box answers (box_quick.h: gq_plane_ok) are sized for planes that are zero or at least 2^-60 in magnitude — there the
+    /// signs of a ray's plane parameters decide the inside test exactly —, such a tree runs its six face tests every time.
     bool subnormal = false;
     static bool tiny(const Child &c) {
         bool r = false;
-        for (int k = 0; k < 3; k++) r = r || std::fpclassify(c.bmin[k]) == FP_SUBNORMAL || std::fpclassify(c.bmax[k]) == FP_SUBNORMAL;
+        for (int k = 0; k < 3; k++) r = r || !gq_plane_ok(c.bmin[k]) || !gq_plane_ok(c.bmax[k]);
         return r;
     }
     static bool box_in_box(const float *cmin, const float *cmax, const float *bmin, const float *bmax) {

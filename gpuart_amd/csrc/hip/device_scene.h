@@ -351,14 +351,14 @@ GD_FN bool aabb_entry(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float &pos, bool 
     return inside | hit;
 }
 
-/// The quick answer for one box (box_quick.h) on aabb_entry's own plane parameters; `cs` = gq_ray_slack of the ray. True: `hit` and
-/// `pos` are what aabb_entry returns (and the box is not odd). False: withdrawn — ask aabb_entry.
+/// The quick answer for one box (box_quick.h) on aabb_entry's own plane parameters — the inside answer included: for the rays and
+/// trees the slack vets, the signs of the parameters decide it as the reference's comparisons do; `cs` = gq_ray_slack of the ray. True:
+/// `hit` and `pos` are what aabb_entry returns (and the box is not odd). False: withdrawn — ask aabb_entry.
 GD_FN bool box_quick(const Ray &r, F3 rdiv, F3 bmin, F3 bmax, float cs, float &pos, bool &hit) {
-    const bool inside = within(r.o.x, bmin.x, bmax.x) & within(r.o.y, bmin.y, bmax.y) & within(r.o.z, bmin.z, bmax.z);
     const float k0 = (bmin.x - r.o.x) * rdiv.x, k1 = (bmax.x - r.o.x) * rdiv.x;
     const float k2 = (bmin.y - r.o.y) * rdiv.y, k3 = (bmax.y - r.o.y) * rdiv.y;
     const float k4 = (bmin.z - r.o.z) * rdiv.z, k5 = (bmax.z - r.o.z) * rdiv.z;
-    return gq_box(inside, k0, k1, k2, k3, k4, k5, fabsf(rdiv.x), fabsf(rdiv.y), fabsf(rdiv.z), cs, pos, hit);
+    return gq_box(k0, k1, k2, k3, k4, k5, fabsf(rdiv.x), fabsf(rdiv.y), fabsf(rdiv.z), cs, pos, hit);
 }
 
 #ifdef GD_QUICK_CHECK

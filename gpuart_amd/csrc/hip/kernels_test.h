@@ -63,8 +63,7 @@ __global__ void k_test_aabb(const float4 *rs, const float4 *rd, const float4 *bm
         // as trav_step_box tests a box of a regular tree: the quick answer (box_quick.h, the slack sized by this box's own planes —
         // the tightest a tree could have), and the six face tests where it is withdrawn
         const float pmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(hi.x))), fmaxf(fabsf(hi.y), fabsf(hi.z)));
-        auto tiny = [](float v) { const uint32_t b = __float_as_uint(v); return (b & 0x7f800000u) == 0 && (b & 0x007fffffu) != 0; };  // (a subnormal plane: converter.h)
-        const bool sub = tiny(lo.x) | tiny(lo.y) | tiny(lo.z) | tiny(hi.x) | tiny(hi.y) | tiny(hi.z);
+        const bool sub = !(gq_plane_ok(lo.x) & gq_plane_ok(lo.y) & gq_plane_ok(lo.z) & gq_plane_ok(hi.x) & gq_plane_ok(hi.y) & gq_plane_ok(hi.z));  // (as converter.h)
         const float cs = gq_ray_slack((GD_QUICK_BOXES && quick && !sub) ? gq_slack_of_tree(pmax) : __builtin_inff(), r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
         if (!box_quick(r, rdiv, lo, hi, cs, pos, h)) h = aabb_entry(r, rdiv, lo, hi, pos);
     } else

@@ -243,7 +243,7 @@ int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_op
  * bit 1: some box does not bound what it holds by the reference's own formulas (a child outside its parent, a primitive outside its
  *        leaf's box, a negative radius, cone constants that contradict its centres, coordinates beyond 2^20) — with either bit the
  *        tree is walked in the reference's order throughout; with neither the fast kernels visit the nearer child first;
- * bit 2: some box plane is a subnormal number (no quick box answers: below);
+ * bit 2: some box plane lies within 2^-60 of zero without being zero, subnormal numbers included (no quick box answers: below);
  * bits 8-11: the primitive types present. GPUART_HIP_ERR_ARG for a malformed tree (gpuart_hip_last_error says why). */
 int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flags);
 

@@ -22,11 +22,12 @@ def test_standing_quick_answers_are_the_reference_answers(tmp_path):
     assert r.returncode == 0 and "32000000 boxes, 0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     # the soak means something: the answer stands for a fair share of every class
     for line in r.stdout.splitlines()[:8]:
-        assert float(line.split("quick answer stands")[1].split("%")[0]) > 15.0, line  # (the hostile and zero-component classes withdraw most: ~20 %)
+        assert float(line.split("quick answer stands")[1].split("%")[0]) > 10.0, line  # (the hostile and zero-component classes withdraw most: ~15 %)
 
 
-@pytest.mark.parametrize("scale", ["0.01f", "0.0f"])
-def test_the_soak_has_teeth(tmp_path, scale):
-    """With the slack constant cut to a hundredth (or to nothing) the same soak must find answers that stand and are wrong."""
-    r = subprocess.run([build(tmp_path, "qbc_cut", ["-DQBC_CS_SCALE=" + scale]), "4", "4", "3"], capture_output=True, text=True)
+@pytest.mark.parametrize("cut", ["-DQBC_CS_SCALE=0.01f", "-DQBC_CS_SCALE=0.0f", "-DGQ_RHO=0.0f", "-DGQ_NO_TINY_ORIGIN_GUARD"])
+def test_the_soak_has_teeth(tmp_path, cut):
+    """With the slack constant cut to a hundredth (or to nothing), without the relative margin, or without the guard that keeps rays with a
+    tiny non-zero origin component away from the sign-based inside answer, the same soak must find answers that stand and are wrong."""
+    r = subprocess.run([build(tmp_path, "qbc_cut", [cut]), "4", "4", "3"], capture_output=True, text=True)
     assert r.returncode == 1 and "MISMATCH" in r.stderr, r.stdout[-800:]

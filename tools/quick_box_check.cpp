@@ -58,11 +58,10 @@ static bool ref_aabb(V3 o, V3 d, V3 rdiv, V3 lo, V3 hi, float &pos) {
 // ---- the quick answer exactly as device_scene.h assembles it ---------------------------------------------------------------
 static bool quick(V3 o, V3 d, V3 rdiv, V3 lo, V3 hi, float cs_tree, float &pos, bool &hit) {
     const float cs = gq_ray_slack(cs_tree, o.x, o.y, o.z, d.x, d.y, d.z, rdiv.x, rdiv.y, rdiv.z);
-    const bool inside = (gq_med3(o.x, lo.x, hi.x) == o.x) & (gq_med3(o.y, lo.y, hi.y) == o.y) & (gq_med3(o.z, lo.z, hi.z) == o.z);
     const float k0 = (lo.x - o.x) * rdiv.x, k1 = (hi.x - o.x) * rdiv.x;
     const float k2 = (lo.y - o.y) * rdiv.y, k3 = (hi.y - o.y) * rdiv.y;
     const float k4 = (lo.z - o.z) * rdiv.z, k5 = (hi.z - o.z) * rdiv.z;
-    return gq_box(inside, k0, k1, k2, k3, k4, k5, gq_abs(rdiv.x), gq_abs(rdiv.y), gq_abs(rdiv.z), cs, pos, hit);
+    return gq_box(k0, k1, k2, k3, k4, k5, gq_abs(rdiv.x), gq_abs(rdiv.y), gq_abs(rdiv.z), cs, pos, hit);
 }
 
 struct Rng {
@@ -86,7 +85,9 @@ static float nudge(float v, int ulps) {  // moves v by `ulps` representable step
 static float flushed(float v) { return std::fabs(v) < 1.17549435e-38f ? 0.0f * v : v; }
 
 static const float SCALES[] = {1.0f, 1.0f, 5.0f, 5.0f, 0.01f, 1.0e-3f, 100.0f, 1.0e4f, 1048576.0f, 1.0e-20f};
-static const float SPECIAL[] = {0.0f, -0.0f, 1.0e-39f, 1.0e30f, -1.0e30f, 3.0e38f, INFINITY, -INFINITY, NAN, 1.0e19f, 1.0e-30f, 1048576.0f, 2.0e6f};
+static const float SPECIAL[] = {0.0f, -0.0f, 1.0e-39f, 1.0e30f, -1.0e30f, 3.0e38f, INFINITY, -INFINITY, NAN, 1.0e19f, 1.0e-30f, 1048576.0f, 2.0e6f,
+                                -1.0e-37f, 2.0e-37f, -3.0e-35f, 1.0e-33f, -1.0e-20f};
+static const int NSPECIAL = sizeof(SPECIAL) / sizeof(SPECIAL[0]);
 
 struct Stats { uint64_t n = 0, sure = 0, sure_hit = 0, sure_in = 0, bad = 0, ref_hit = 0; };
 
@@ -142,10 +143,16 @@ static void worker(uint64_t seed, uint64_t iters, Stats *out) {
                 if (cls == 6 && g.below(3) == 0) dd[k] = 0.0f * (g.below(2) ? 1.0f : -1.0f);
                 if (g.below(8) == 0) dd[k] = nudge(dd[k], g.below(5) - 2);
             }
+            if (cls == 5) {  // tiny origin components beside planes that are exactly 0, small direction components: the inside answer's flush corner
+                for (int k = 0; k < 3; k++) {
+                    if (g.below(3) == 0) oo[k] = (g.below(2) ? 1.0f : -1.0f) * (g.below(2) ? 1.0e-37f : 3.0e-33f) * (1.0f + g.uni());
+                    if (g.below(3) == 0) dd[k] = (g.below(2) ? 1.0f : -1.0f) * 1.0e3f * (1.0f + g.uni());
+                }
+            }
             if (cls == 7) {  // hostile numbers
                 for (int k = 0; k < 3; k++) {
-                    if (g.below(4) == 0) oo[k] = SPECIAL[g.below(13)];
-                    if (g.below(4) == 0) dd[k] = SPECIAL[g.below(13)];
+                    if (g.below(4) == 0) oo[k] = SPECIAL[g.below(NSPECIAL)];
+                    if (g.below(4) == 0) dd[k] = SPECIAL[g.below(NSPECIAL)];
                 }
             }
             o = V3{oo[0], oo[1], oo[2]};
@@ -155,6 +162,9 @@ static void worker(uint64_t seed, uint64_t iters, Stats *out) {
         float pmax = 0;
         for (int k = 0; k < 3; k++) pmax = std::fmax(pmax, std::fmax(std::fabs((&lo.x)[k]), std::fabs((&hi.x)[k])));
         if (g.below(4) == 0) pmax *= 1.0f + 10.0f * g.uni();  // (a tree's bound is looser than one box's)
+        bool planes_ok = true;  // what the converter checks per tree (gq_plane_ok): no plane within 2^-60 of zero without being zero
+        for (int k = 0; k < 3; k++) planes_ok = planes_ok && gq_plane_ok((&lo.x)[k]) && gq_plane_ok((&hi.x)[k]);
+        if (!planes_ok) pmax = NAN;  // -> slack +inf
 #ifdef QBC_CS_SCALE  // teeth test: a slack constant that is too small must produce mismatches
         const float cs = gq_slack_of_tree(pmax) * QBC_CS_SCALE;
 #else
