@@ -867,10 +867,23 @@ GD_FN void thin_fetch(const Scene &sc, const Trav &t, uint32_t sub, ThinFetch &p
     }
 }
 
+#ifndef GD_THIN_PREFETCH
+#define GD_THIN_PREFETCH 1
+#endif
+/// Where a thin-wave step may warm the vector L1 for a child it STACKS (a pop will fetch that child's record — or a leaf's first
+/// primitive record — many dependent steps later; in a draining wave that fetch is a round trip to the L2 on the ray's critical path,
+/// and the memory system is idle): one 4-byte `global_load_lds` per stacked child into a sink in LDS that nobody reads — a load without
+/// a destination register, so nothing has to stay alive for it. `sink` == nullptr: no prefetch.
+struct ThinPrefetch {
+    const float4 *recs, *prims;
+    uint32_t *sink;  ///< LDS, BLOCK words of this wave
+};
+
 /// One interior-node visit of a ray carried by M replicas (`sub` = this lane's index among them), on the parts of the record the
 /// replicas hold in `pf` (thin_fetch). Precondition: DESCEND.
 template <int M, bool NEAREST = false>
-GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, float slack, bool ordered = true) {
+GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, const ThinFetch &pf, float slack, bool ordered = true,
+                                 ThinPrefetch warm = ThinPrefetch{nullptr, nullptr, nullptr}) {
     const float INF = __builtin_inff();
     float e;  // this lane's box: entry parameter, GD_ENTRY_MISS when not hit
     uint32_t ref_lo, ref_hi;
@@ -927,6 +940,10 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
         StackEntry s;
         s.ref = ref_hi; s.pe = t.entry; s.he = eh;
         st.push(s, writer);
+        if (GD_THIN_PREFETCH && warm.sink && writer && !(el > limit)) {  // (if the other child is not entered either, this one is popped at once)
+            const float4 *line = (ref_hi & GD_REF_LEAF) ? warm.prims + 3 * (size_t)(ref_hi & GD_REF_INDEX) : warm.recs + 4 * (size_t)ref_hi;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)line, (__attribute__((address_space(3))) void *)warm.sink, 4, 0, 0);
+        }
     }
     if (!(el > limit)) {
         trav_enter(t, ref_lo, el);
@@ -937,10 +954,10 @@ GD_FN void trav_step_box_thin_on(F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, 
 
 /// The same, fetching the record itself (the loops that do not fetch ahead).
 template <int M, bool NEAREST = false>
-GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, bool ordered = true) {
+GD_FN void trav_step_box_thin(const Scene &sc, F3 ro, F3 rd, F3 rdiv, Trav &t, TravStack &st, uint32_t sub, bool ordered = true, uint32_t *sink = nullptr) {
     ThinFetch pf;
     thin_fetch<M>(sc, t, sub, pf);
-    trav_step_box_thin_on<M, NEAREST>(ro, rd, rdiv, t, st, sub, pf, sc.box_slack, ordered);
+    trav_step_box_thin_on<M, NEAREST>(ro, rd, rdiv, t, st, sub, pf, sc.box_slack, ordered, ThinPrefetch{sc.recs, sc.prims, sink});
 }
 
 /// The pending leaf of a ray carried by M replicas, then the pop. A leaf of one or two triangles is split between the halves

@@ -102,6 +102,7 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
       unsigned long long *gcounters, TraceTuning tune, uint32_t *cursor) {
     __shared__ uint2 ring_a[GD_RING * BLOCK];
     __shared__ float ring_b[GD_RING * BLOCK];
+    __shared__ uint32_t warm_sink[BLOCK];  // where the thin-wave steps' L1-warming loads land (device_scene.h ThinPrefetch); never read
     __shared__ uint32_t ready[RUN_RQ], shadeq[RUN_SQ];
     TravStack st = make_stack(ring_a, ring_b, spill, gridDim.x * BLOCK);
     const uint32_t total = b.n_slots * b.batch;  // a multiple of 64: one chunk = 64 consecutive path slots (few pixels x the run's passes)
@@ -362,13 +363,13 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
 #endif
 #if RUN_PIPE
                     if (t.state == TRAV_DESCEND) {
-                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, sc.box_slack, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
+                        trav_step_box_thin_on<W, NEAR>(ro, rd, rdiv, t, st, sub, pf, sc.box_slack, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)), ThinPrefetch{sc.recs, sc.prims, warm_sink});
                         thin_fetch<W>(sc, t, sub, pf);
                         fresh = (t.state & 8) != 0;
                     }
                     const bool leaf_now = (t.state & 1) != 0 && !fresh;
 #else
-                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)));
+                    if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)), warm_sink);
                     const bool leaf_now = (t.state & 1) != 0;
 #endif
 #ifdef GD_RUN_TIMELINE

@@ -393,6 +393,8 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
+                    // (no L1-warming loads for stacked children here, unlike k_run: the end of a k_trace launch overlaps the launches of
+                    //  other pass lanes, the memory system is busy, and the extra requests cost 6 % of a pass — profiles/r04/thin_prefetch.txt)
                     if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, !shadow && !refwalk);
                     const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
@@ -664,6 +666,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
                 constexpr int W = decltype(width)::value;
                 constexpr unsigned long long LEAD = W == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
                 for (;;) {
+                    // (k_run's L1-warming loads for stacked children buy nothing here: 0.641 / 1.477 against 0.639 / 1.458 ms per 1080p / 4K frame)
                     if (t.state == TRAV_DESCEND) trav_step_box_thin<W, NEAR>(sc, ro, rd, rdiv, t, st, sub, stage != DL_SUN && !refwalk);
                     const unsigned long long at_leaf = __ballot((t.state & 1) != 0) & LEAD;
                     unsigned long long busy = __ballot(t.state != TRAV_DONE) & LEAD;
