@@ -6,7 +6,7 @@
 // answer is the slab entry — the largest of the three nearer-plane parameters, if it does not exceed the smallest of the farther
 // ones. In fp32 the two differ exactly where a parameter of one axis comes within rounding of a plane of another (rays through
 // edges and corners, origins on a plane). This file decides from the six plane parameters alone, with margins that cover every
-// rounding of the reference's own expressions, whether that can be the case — ~50 VALU — and withdraws when it can.
+// rounding of the reference's own expressions, whether that can be the case — 46 VALU — and withdraws when it can.
 //
 // Notation, per axis a: o, d the ray's origin and direction component, r = fl(1/d) (the caller's rdiv), lo <= hi the box planes,
 //   k_lo = fl(fl(lo - o) * r), k_hi likewise       the reference's plane parameters (:258-351), bit for bit what aabb_entry computes
