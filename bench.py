@@ -213,13 +213,22 @@ def main():
     # staged through host memory by sharding.gather_shares_host); the driver's runs use RCCL ("nccl").
     backend = os.environ.get("GPUART_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(1, torch.cuda.device_count())
+    # Every step of a rank that waits for other ranks is a named phase (gpuart_hip_phase_begin: one line on stderr when it begins and
+    # ends, and the library's watchdog thread behind it — a phase that outlives its bound prints the phase and the library's recent
+    # errors and ends THIS rank with exit code 86; nothing is re-executed in a process that has touched the GPU). N = 1 has no such step.
+    phase_ms = int(float(os.environ.get("GPUART_BENCH_PHASE_TIMEOUT_S", "300")) * 1000)
+
+    def phase(name, ms=None):
+        return B.phase("rank %d: %s" % (rank, name), phase_ms if ms is None else ms)
+
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        with phase("torch.distributed init (%s)" % backend):
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     xdev = dev if backend == "nccl" else torch.device("cpu")  # where tensors exchanged through torch.distributed live
     torch.cuda.set_device(dev)
@@ -243,8 +252,12 @@ def main():
                 idt.copy_(torch.frombuffer(bytearray(B.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             try:
-                be.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+                with phase("communicator init (gpuart_hip_comm_init = ncclCommInitRank)"):
+                    be.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
             except B.HipError as e:
+                if e.code == B.ERR_TIMEOUT:  # ncclCommInitRank never returned (a rank is missing): its thread is parked, nothing to fall back to
+                    print("bench.py rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+                    os._exit(3)
                 gather_note = "gpuart_hip_comm_init failed (%s): gathered through torch.distributed point-to-point instead" % e
             # all ranks must take the same exchange path: one rank's failure moves every rank to the fallback
             ok = torch.tensor([1 if gather_note is None else 0], dtype=torch.int32, device=xdev)
@@ -256,6 +269,8 @@ def main():
             gather_note = "GPUART_BENCH_BACKEND=%s rehearsal: gathered through host memory" % backend
 
     # ---- exact work counts: the same K passes, untimed; reference-defined (mode 1) and as the fast mode executes them (mode 4) ----
+    replay_frames = {}
+
     def count(mode):
         r.set_seed(5489)
         be.set_mode(mode)
@@ -263,6 +278,7 @@ def main():
         run_passes(r, K)
         be.finish()
         c = be.counters(reset=True)
+        replay_frames[mode] = r.read_radiance(False)  # this rank's accumulator after the K passes (frames_verified below)
         be.set_mode(0)
         return [c.rays, c.nodes, c.prim_tests[0], c.prim_tests[1], c.prim_tests[2], c.prim_tests[3], c.segments,
                 c.algorithmic_bytes() + 32 * W * th * K, c.rewalks, c.box_steps]
@@ -308,8 +324,9 @@ def main():
             store.set("gpuart_arrived_%s_%d" % (tag, rank), "1")
         if gather_note is None:
             try:
-                be.gather(1, divide_by, 0, full.data_ptr() if rank == 0 else 0)
-                be.wait(int(args.gather_timeout * 1000))
+                with phase("frame gather #%s (gpuart_hip_gather + gpuart_hip_wait)" % tag, int(args.gather_timeout * 1000) + phase_ms):
+                    be.gather(1, divide_by, 0, full.data_ptr() if rank == 0 else 0)
+                    be.wait(int(args.gather_timeout * 1000))
             except B.HipError as e:
                 if e.code == B.ERR_TIMEOUT:
                     print("bench.py rank %d: the frame gather did not complete within %.0f s (%s); ranks that never reached gather #%s: %s"
@@ -386,6 +403,19 @@ def main():
     pass_ms, passes = be.kernel_time(0, reset=True)
     kernel_ms, launches = be.kernel_time(1, reset=True)
     be.set_timing(1)
+    # ---- the frames that were just timed, checked (untimed): the accumulator the LAST timed repetition left on this rank against the
+    #      accumulator of the mode-1 replay of the same K passes — reference-order walks, every reference query performed, the kernels
+    #      the oracle is held against in tests/ — bit for bit; the mode-4 replay (whose ray count is `value`'s numerator) likewise. A
+    #      line whose timed kernels rendered something else is not a measurement: the run exits non-zero after printing it.
+    timed_frame = r.read_radiance(False)
+    bad = {m: int((timed_frame[..., :3].view(np.uint32) != f[..., :3].view(np.uint32)).any(-1).sum()) for m, f in replay_frames.items()}
+    rows_crc = int(np.bitwise_xor.reduce(timed_frame[..., :3].view(np.uint32).reshape(-1)))
+    frames_bad = torch.tensor([bad.get(1, -1), bad.get(4, -1)], dtype=torch.float64, device=xdev)
+    if dist is not None:
+        dist.all_reduce(frames_bad)
+    frames_bad = [int(x) for x in frames_bad.tolist()]
+    frames_verified = frames_bad == [0, 0]
+    del replay_frames, timed_frame
     order = sorted(range(len(reps)), key=lambda k: reps[k][0])
     med = order[len(order) // 2]
     elapsed = reps[med][0]
@@ -414,15 +444,26 @@ def main():
                 multi["rccl_mapped"] = None
         multi["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
 
+    def comm_destroy():
+        """gpuart_hip_comm_destroy (= ncclCommDestroy) as a watched phase; a destroy that does not return ends the rank (exit 3)."""
+        try:
+            with phase("communicator destroy (gpuart_hip_comm_destroy = ncclCommDestroy)"):
+                be.comm_destroy()
+        except B.HipError as e:
+            print("bench.py rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+            if e.code == B.ERR_TIMEOUT:
+                os._exit(3)
+            raise
+
     verify = dist is not None and not args.no_verify_gather
     if dist is not None and gather_note is None and not verify:
-        be.comm_destroy()  # every rank, while all of them are still alive
+        comm_destroy()  # every rank, while all of them are still alive
     if rank != 0:
         if dist is not None:
             if verify:
                 dist.barrier()  # rank 0 is still checking the gathered frame
                 if gather_note is None:
-                    be.comm_destroy()
+                    comm_destroy()
             dist.destroy_process_group()
         return
 
@@ -443,7 +484,7 @@ def main():
         print("verify-gather: gathered %d interleaved row sets == single-rank frame: %s" % (world, gather_verified), file=sys.stderr)
         dist.barrier()
         if gather_note is None:
-            be.comm_destroy()
+            comm_destroy()
 
     # ---- one pass alone, observed after it (the reference's interactive loop, src/main.cpp:549-599): frame time, not throughput ----
     single_ms = None
@@ -467,7 +508,7 @@ def main():
     roof = BL.assemble_roofline(ms_step, passes_profiled, prof, trace,
                                 executed={"nodes": exe[1] / K, "steps": exe[9] / K, "algorithmic_bytes": exe[7] / K},
                                 reference={"nodes": nodes / K, "algorithmic_bytes": alg_bytes / K},
-                                kernel_events=(kernel_ms, launches, elapsed_all))
+                                kernel_events=(kernel_ms, launches, elapsed_all), passes_timed=K * len(reps))
     roof["source"] = source
     roof["kernel_ms_summed_per_pass"] = round(kernel_ms / (K * len(reps)), 4)  # HIP events, all repetitions
 
@@ -533,6 +574,12 @@ def main():
         "mrays_reference_defined_per_s": round(rays / elapsed / 1e6, 3),
         "mrays_reference_defined_note": "every closest-hit query the REFERENCE performs for these passes (mode-1 replay) over the same wall "
                                         "time: what the images are worth in the reference's own work, not work this run performed",
+        "frames_verified": frames_verified,
+        "frames_verified_note": ("after the last timed repetition every rank's accumulator (its K timed passes) == the accumulator of the untimed mode-1 "
+                                 "replay (reference-order walks, every reference query) and of the mode-4 replay (the one that counts `value`'s rays) of "
+                                 "the same passes and seeds, bit for bit" if frames_verified else
+                                 "MISMATCH: %d pixels differ from the mode-1 replay, %d from the mode-4 replay (summed over ranks): this line is not a measurement" % tuple(frames_bad)),
+        "frames_xor_of_rank0_accumulator_bits": "%08x" % rows_crc,
         "multi_gpu": multi,
         "nodes_per_step": nodes / K, "nodes_executed_per_step": exe[1] / K,
         "rewalked_queries_per_step": exe[8] / K,
@@ -553,6 +600,8 @@ def main():
     shutil.rmtree(tmpdir, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+    if not frames_verified:
+        sys.exit("bench.py: the timed frames differ from the replays' (frames_verified_note)")
     if gather_verified is False:
         sys.exit("bench.py: the gathered frame differs from rank 0's own whole-frame render (multi_gpu.gather_verified_note)")
 

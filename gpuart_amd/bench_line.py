@@ -2,10 +2,12 @@
 subprocess — so that tests/test_bench_line.py can drive it on stubbed counters: a definition that drifts (a numerator and a
 denominator describing different schedules, a fraction of the wrong peak) fails a test instead of reaching the driver.
 
-What binds the path: branchy scalar fp32 per ray on a cache-resident tree. The headline is therefore the share
-of the chip's fp32 LANE slots that do work — VALU issue-slot share x the fraction of lanes active in an issued instruction — and
-beside it everything needed to read it: the issue-slot share itself, the wave-state split of the dominant kernel (executing /
-s_waitcnt / waiting to issue), vector-L1 accesses, node visits, HBM traffic against the algorithmic bytes, and per-kernel rows."""
+The top level follows the bench contract to the letter: bound "hbm", achieved = algorithmic bytes of one launch of the
+dominant kernel / its average launch duration, peak 8 TB/s, traffic = PMC HBM bytes per launch. What really binds the path (DESIGN.md
+section 4) — branchy scalar fp32 per ray on a cache-resident tree — is told by the blocks beside it: the share of the chip's fp32 LANE
+slots that do work (`lane_slots`: VALU issue-slot share x the fraction of lanes active in an issued instruction; the top-level figure of
+rounds 3-4), the issue-slot share itself, the wave-state split of the dominant kernel (executing / s_waitcnt / waiting to issue),
+vector-L1 accesses, node visits against the micro-benchmarked step, HBM traffic against the algorithmic bytes, and per-kernel rows."""
 import csv
 import glob
 import os
@@ -91,7 +93,19 @@ def wave_states(c):
             "issue_wait": _r(c.get("SQ_WAIT_INST_ANY", 0.0) / w), "wave_cycles_per_pass": None}
 
 
-def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, reference, kernel_events, dominant="k_trace"):
+# Every block of the roofline object that carries achieved / peak / frac, with the quantity BOTH are counted in: a ratio of two
+# different quantities is a bug (rounds 2-4 divided box tests by a peak in node visits, two box tests per visit — their 0.87-0.90
+# were 0.44-0.45). tests/test_bench_line.py::test_every_ratio_divides_like_by_like holds every block to its entry here.
+RATIO_QUANTITIES = {
+    "": "algorithmic bytes of one launch of the dominant kernel per second of that launch",
+    "lane_slots": "fp32 lane-operations per second",
+    "valu_issue": "wave64 VALU instructions per second",
+    "l1_accesses": "vector-L1 cache accesses per second",
+    "node_visits": "interior-node visits (record fetches) per second",
+}
+
+
+def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, reference, kernel_events, dominant="k_trace", passes_timed=None):
     """The `roofline` object of the bench line.
       ms_per_step      : wall time of one timed pass (median repetition), ms
       passes_profiled  : passes every profiled child rendered (the counters' denominator: the child renders the TIMED shape —
@@ -101,32 +115,49 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
       executed / reference : dicts with nodes (box tests), algorithmic_bytes per pass (device counters of the fast mode / of the reference's
                          work); executed also steps (interior-node visits = record fetches)
       kernel_events    : (summed ms, launches, timed seconds) of the dominant kernel's launches measured live with HIP events
-    Every fraction is achieved / peak of the SAME quantity over the SAME passes; None where a counter is missing."""
+      passes_timed     : passes rendered while those events were collected (K x repetitions)
+    Top level = the contract of the task statement: bound "hbm"; achieved = ALGORITHMIC bytes one launch of the dominant
+    kernel processes / that kernel's average launch duration (HIP events on its own stream, live); peak = 8 TB/s; traffic = HBM bytes
+    per launch from the PMC counters. Beside it the views that say what really binds a cache-resident tree (`lane_slots`, `valu_issue`,
+    `l1_accesses`, `node_visits`, wave states, per-kernel rows).
+    Every fraction is achieved / peak of the SAME quantity (RATIO_QUANTITIES) over the SAME passes; None where a counter is missing."""
     s = ms_per_step * 1e-3
     n = float(max(1, passes_profiled))
     ev_ms, ev_n, ev_span = kernel_events
-    roof = {"bound": "valu_lanes", "achieved": None, "peak": round(VALU_PEAK_GINSTR * 64 / 1e3, 2), "unit": "T fp32 lane-operations/s", "frac": None,
-            "traffic": None,
-            "definition": "useful share of the chip's fp32 lane slots: wave64 VALU instructions of every kernel of a pass / ms_per_step x the "
-                          "lanes active in them (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), against 1024 SIMDs x 2.4 GHz / 2 cycles per "
-                          "wave64 VALU instruction x 64 lanes. = valu_issue.frac x valu_issue.lane_util. The path is branchy scalar fp32 per ray "
-                          "on a cache-resident tree: neither HBM nor MFMA is its roof (hbm.* and the algorithmic bytes are kept beside it, "
-                          "SURVEY.md 8(d)); `kernels` and `%s_wave_states` say where the rest of the slots go" % dominant,
-            "frac_note": "a share of lane SLOTS spent on instructions, not a figure of merit: it fell from 0.34 to 0.26 when the box test went from "
-                         "~100 to ~50 instructions for the same boxes (quick box answers, csrc/hip/box_quick.h: same rays, same node visits, 11 % less "
-                         "time). Compare builds by ms_per_step; what the step lacks to its micro-benchmarked rate is node_visits.frac",
+    launches_per_pass = (ev_n / float(passes_timed)) if (passes_timed and ev_n) else None
+    avg_ms = ev_ms / ev_n if ev_n else None
+    bytes_per_launch = executed["algorithmic_bytes"] / launches_per_pass if launches_per_pass else None
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if (bytes_per_launch and avg_ms) else None
+    roof = {"bound": "hbm", "achieved": _r(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _r(achieved / HBM_PEAK_GBS) if achieved else None,
+            "traffic": None, "quantity": RATIO_QUANTITIES[""],
+            "definition": "SURVEY.md 8(d) / the bench contract: algorithmic bytes (48 B per box tested + 32/48/64/80 B per primitive tested + 32 B per pixel "
+                          "and pass, as the fast mode EXECUTES them: device counters of an untimed mode-4 replay of the timed passes) of ONE launch of the "
+                          "dominant kernel (bytes per pass / its launches per pass) / that kernel's average launch duration, measured live with HIP events on "
+                          "the stream it is launched on; peak = 8 TB/s HBM3E; traffic = HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE of "
+                          "that kernel, KB -> bytes, / its launches). Reading it: the tree (8.7 MB) is served by L1 / L2 / Infinity Cache, so algorithmic "
+                          "bytes are not HBM bytes (`traffic` is ~7x smaller) and up to 8 launches overlap (`kernel_concurrency`): the wall-clock "
+                          "algorithmic rate is hbm.algorithmic_rate_executed, above the HBM peak. What binds the kernel is in lane_slots / node_visits / "
+                          "%s_wave_states" % dominant,
+            "per_launch": {"algorithmic_bytes": bytes_per_launch, "avg_ms": _r(avg_ms, 5), "launches_per_pass": _r(launches_per_pass, 3), "traffic_bytes": None},
+            "lane_slots": {"achieved": None, "peak": round(VALU_PEAK_GINSTR * 64 / 1e3, 2), "unit": "T fp32 lane-operations/s", "frac": None,
+                           "quantity": RATIO_QUANTITIES["lane_slots"],
+                           "definition": "useful share of the chip's fp32 lane slots (the top-level figure of rounds 3-4): wave64 VALU instructions of every "
+                                         "kernel of a pass / ms_per_step x the lanes active in them (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), against 1024 "
+                                         "SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction x 64 lanes = valu_issue.frac x valu_issue.lane_util. A share of "
+                                         "lane SLOTS spent on instructions, not a figure of merit: it falls when the same boxes are tested with fewer instructions"},
             "kernel": dominant + " (closest-hit + Sun-shadow BVH-query launches of the wavefront pipeline)",
             "kernel_avg_ms": _r(ev_ms / max(1, ev_n), 5), "kernel_launches": ev_n,
             "kernel_concurrency": _r(ev_ms / (ev_span * 1e3), 3) if ev_span else None,
             "kernel_avg_ms_note": "HIP events around every launch of that kernel on the stream it is launched on, during the timed passes; launches of "
                                   "up to 8 pass lanes overlap (`kernel_concurrency` = summed kernel time / wall time), so per-launch figures are diagnostics",
-            "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s", "achieved": None, "frac": None,
+            "valu_issue": {"peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instructions/s", "achieved": None, "frac": None, "quantity": RATIO_QUANTITIES["valu_issue"],
                            "peak_measured": VALU_MEASURED_GINSTR, "peak_same_instruction_mix": VALU_SAME_MIX_GINSTR,
                            "definition": "SQ_INSTS_VALU of every kernel of a pass / ms_per_step: a share of ISSUE SLOTS (wasted instructions raise it)"},
-            "l1_accesses": {"peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "achieved": None, "frac": None,
+            "l1_accesses": {"peak": L1_PEAK_GACC, "unit": "G vector-L1 (TCP) cache accesses/s", "achieved": None, "frac": None, "quantity": RATIO_QUANTITIES["l1_accesses"],
                             "definition": "TCP_TOTAL_CACHE_ACCESSES_sum of every kernel of a pass / ms_per_step against the highest rate tools/ubench "
                                           "reaches on the box with the product's node-fetch shape (one access per cycle and CU: 614.4)"},
-            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G record visits/s (lane level: one lane fetching one 64-byte record and testing its two boxes)",
+            "node_visits": {"peak": STEP_PEAK_GVISITS, "unit": "G record visits/s (lane level: one lane fetching one node record and testing its two boxes)",
+                            "quantity": RATIO_QUANTITIES["node_visits"],
                             "achieved": _r(executed["steps"] / s / 1e9, 2), "frac": _r(executed["steps"] / s / 1e9 / STEP_PEAK_GVISITS),
                             "box_tests_per_s": _r(executed["nodes"] / s / 1e9, 2),
                             "definition": "interior-node visits the fast mode executes (device counter box_steps: one record fetch + two box tests each) / "
@@ -167,8 +198,8 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
         if valu_t.get("SQ_ACTIVE_INST_VALU"):
             lu = valu_t["SQ_THREAD_CYCLES_VALU"] / (64.0 * valu_t["SQ_ACTIVE_INST_VALU"])
             vi["lane_util"] = _r(lu)
-            roof["achieved"] = _r(instr * 64 * lu / s / 1e12, 3)
-            roof["frac"] = _r(instr * lu / s / 1e9 / VALU_PEAK_GINSTR)
+            roof["lane_slots"]["achieved"] = _r(instr * 64 * lu / s / 1e12, 3)
+            roof["lane_slots"]["frac"] = _r(instr * lu / s / 1e9 / VALU_PEAK_GINSTR)
     if tcp_t.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         acc = tcp_t["TCP_TOTAL_CACHE_ACCESSES_sum"] / n
         l1 = roof["l1_accesses"]
@@ -185,7 +216,12 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
         # estimate), both counters in KB; Infinity-Cache hits are counted too (the guide's HBM / rocprofv3 section)
         fetch, write = fetch_t.get("FETCH_SIZE", 0.0) / n, write_t.get("WRITE_SIZE", 0.0) / n
         traffic = (2.0 * fetch + write) * 1024.0
-        roof["traffic"] = traffic
+        # the contract's `traffic`: HBM bytes of ONE launch of the dominant kernel (its own counters / its launches in the profiled children)
+        dom_launches = trace[dominant][0] if (trace and dominant in trace) else 0
+        if dom_launches:
+            dom_traffic = (2.0 * fetch_f.get(dominant, {}).get("FETCH_SIZE", 0.0) + write_f.get(dominant, {}).get("WRITE_SIZE", 0.0)) * 1024.0 / dom_launches
+            roof["traffic"] = dom_traffic
+            roof["per_launch"]["traffic_bytes"] = dom_traffic
         roof["hbm"].update({"traffic_bytes_per_pass": traffic, "FETCH_SIZE_KB_per_pass": fetch, "WRITE_SIZE_KB_per_pass": write,
                             "traffic_rate": _r(traffic / s / 1e9, 1), "traffic_frac": _r(traffic / s / 1e9 / HBM_PEAK_GBS),
                             "traffic_over_algorithmic": _r(traffic / max(1.0, executed["algorithmic_bytes"]), 3)})

@@ -237,12 +237,65 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def phase_begin(name, timeout_ms):
+    """gpuart_hip_phase_begin: names the phase the process enters and arms the library's watchdog (a native thread: it fires
+    whatever the interpreter is doing) — a phase that outlives timeout_ms ends the process with exit code WATCHDOG_EXIT after
+    printing the phase and the library's recent errors."""
+    hip_lib().gpuart_hip_phase_begin(str(name).encode(), C.c_uint32(int(timeout_ms)))
+
+
+def phase_end():
+    hip_lib().gpuart_hip_phase_end()
+
+
+class phase:
+    """with phase("communicator init", 120000): ...   (the phase ends when the block does, exception or not)"""
+
+    def __init__(self, name, timeout_ms):
+        self.name, self.timeout_ms = name, timeout_ms
+
+    def __enter__(self):
+        phase_begin(self.name, self.timeout_ms)
+
+    def __exit__(self, *exc):
+        phase_end()
+        return False
+
+
+WATCHDOG_EXIT = 86
+ERR_TIMEOUT = -4
+
+
+def comm_stuck():
+    """True once an RCCL call of this process has outlived GPUART_HIP_COMM_TIMEOUT_MS (its thread is parked in it)."""
+    return bool(hip_lib().gpuart_hip_comm_stuck())
+
+
+def comm_init_all(backends):
+    """gpuart_hip_comm_init_all: the contexts become the ranks 0..n-1 of one communicator (ncclCommInitAll)."""
+    L = hip_lib()
+    arr = (C.c_void_p * len(backends))(*[b.ctx for b in backends])
+    backends[0]._chk(L.gpuart_hip_comm_init_all(arr, len(backends)))
+
+
+def gather_all_read(backends, which, divide_by, root, W, H):
+    """gpuart_hip_gather_all_read: the frame assembled on the root's device from every context's share, read back (H, W, 4)."""
+    L = hip_lib()
+    arr = (C.c_void_p * len(backends))(*[b.ctx for b in backends])
+    out = np.empty((H, W, 4), np.float32)
+    rc = L.gpuart_hip_gather_all_read(arr, len(backends), which, C.c_float(divide_by), root, _p(out))
+    if rc == ERR_TIMEOUT:
+        _abandoned.append(out)  # the read-back is still queued behind the rows that never came: its target must outlive the call
+    backends[0]._chk(rc)
+    return out
+
+
+_abandoned = []
+
+
 class HipError(RuntimeError):
     """A gpuart_hip_* call returned an error; `code` is the library's (GPUART_HIP_ERR_*: -4 a bounded wait ran out)."""
     code = None
-
-
-ERR_TIMEOUT = -4
 
 
 class Backend:

@@ -44,9 +44,15 @@ Rccl *rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // GPUART_HIP_RCCL_LIBRARY: this file and no other (a site's own build of RCCL; the tests' stand-in whose calls can be made
+        // to never return — tests/stubs/rccl_stub.c — which is how the bounded waits are exercised on one GPU)
+        if (const char *own = getenv("GPUART_HIP_RCCL_LIBRARY")) {
+            r.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { r.err = std::string("cannot load GPUART_HIP_RCCL_LIBRARY: ") + dlerror(); return; }
+        }
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) { r.err = std::string("cannot load librccl: ") + dlerror(); return; }
         auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };

@@ -24,6 +24,7 @@
 #include "converter.h"
 #include "gather.h"
 #include "run_planner.h"
+#include "bounded.h"
 
 // =================================================================================================
 // Host side: context, upload, launches
@@ -40,6 +41,7 @@ __attribute__((constructor)) void request_hw_queues() { setenv("GPU_MAX_HW_QUEUE
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
+    bounded_ns::log_error(code, msg);  // (all threads' recent errors: what the phase watchdog prints, bounded.h)
     return code;
 }
 
@@ -157,6 +159,8 @@ struct gpuart_hip_ctx {
     uint64_t comm_group = 0;          ///< which communicator this context is a rank of: contexts joined by one _comm_init_all (or one
                                       ///< unique id) share it; gpuart_hip_gather_all refuses ranks of different communicators
     uint32_t gather_timeout_ms = 60000;  ///< GPUART_HIP_GATHER_TIMEOUT_MS: bound on the host-side wait for the peers (0: none)
+    bool abandoned = false;           ///< a bounded wait on the primary stream ran out: what is queued there may never complete, so
+                                      ///< every later wait of this context (comm_destroy, destroy) is bounded too
 };
 
 namespace {
@@ -170,6 +174,22 @@ int drain(gpuart_hip_ctx *c) {
     return 0;
 }
 
+
+/// Waits for the context's primary stream, but not for ever: a peer that never arrives must not hang this process.
+int wait_stream(gpuart_hip_ctx *c, uint32_t timeout_ms, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) { c->abandoned = false; return 0; }
+        if (e != hipErrorNotReady) return fail(GPUART_HIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+        if (timeout_ms && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+            c->abandoned = true;  // what is queued on the stream may never complete: later waits of this context stay bounded (destroy included)
+            return fail(GPUART_HIP_ERR_TIMEOUT, std::string(what) + ": not complete after " + std::to_string(timeout_ms) +
+                        " ms (rank " + std::to_string(c->comm_rank) + " of " + std::to_string(c->comm_nranks) + "; a peer has not joined the collective)");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
 }  // namespace
 extern "C" int gpuart_hip_flush(gpuart_hip_ctx *c);
 namespace {
@@ -382,6 +402,7 @@ extern "C" {
 const char *gpuart_hip_last_error(void) { return g_last_error.c_str(); }
 
 int gpuart_hip_destroy(gpuart_hip_ctx *c);
+static int comm_drop(gpuart_hip_ctx *c);
 
 int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     if (!out) return fail(GPUART_HIP_ERR_ARG, "out == NULL");
@@ -448,6 +469,13 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     c->pend_seeds.clear();
+    if (c->abandoned || bounded_ns::stuck().load()) {
+        // the primary stream may hold transfers whose peer never came: one more bounded look, then the context is LEAKED rather
+        // than waited for (its memory goes with the process)
+        if (wait_stream(c, std::min<uint32_t>(c->gather_timeout_ms ? c->gather_timeout_ms : 2000u, 2000u), "gpuart_hip_destroy"))
+            return fail(GPUART_HIP_ERR_TIMEOUT, "gpuart_hip_destroy: the context's stream never drained (a gather was abandoned); the context is leaked, not freed");
+        c->abandoned = false;
+    }
     (void)drain(c);
     for (auto &t : c->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &t : c->free_events) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -458,12 +486,17 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
         for (void *p : lp) if (p) (void)hipFree(p);
         if (l.main) (void)hipStreamDestroy(l.main);
     }
-    if (c->comm && c->comm_owned && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->comm);
+    // A communicator call that never returned (bounded.h) may still be using the communicator and the buffers it was given:
+    // they are left alone, and so is the communicator (the process is about to end; nothing is waited for a second time).
+    const bool comm_stuck = bounded_ns::stuck().load();
+    if (c->comm && !comm_stuck) (void)comm_drop(c);
     void *ptrs[] = {c->d_recs, c->d_prims, c->d_spill, c->d_direct, c->d_accum, c->d_counters, c->d_scratch, c->d_cursor,
-                    c->d_send, c->d_stage, c->d_hello, c->d_tile_order[0], c->d_tile_order[1], c->d_tile_cost};
+                    c->d_tile_order[0], c->d_tile_order[1], c->d_tile_cost};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    void *comm_ptrs[] = {c->d_send, c->d_stage, c->d_hello};
+    for (void *p : comm_ptrs) if (p && !comm_stuck) (void)hipFree(p);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
-    if (c->h_hello) (void)hipHostFree(c->h_hello);  // (after drain: no copy into it is queued any more)
+    if (c->h_hello && !comm_stuck) (void)hipHostFree(c->h_hello);  // (after drain: no copy into it is queued any more)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1016,10 +1049,38 @@ int gpuart_hip_comm_unique_id(void *id128) {
     return 0;
 }
 
-static int comm_drop(gpuart_hip_ctx *c) {
-    if (c->comm && c->comm_owned) (void)rccl()->CommDestroy(c->comm);
-    c->comm = nullptr; c->comm_owned = false; c->comm_nranks = 0; c->comm_rank = 0; c->comm_group = 0;
+/// An RCCL-facing entry point in a process where an earlier RCCL call never returned (bounded.h): refused at once.
+static int comm_layer_ok() {
+    if (bounded_ns::stuck().load())
+        return fail(GPUART_HIP_ERR_TIMEOUT, "the communicator layer of this process is out of service: " + bounded_ns::stuck_in() + " never returned");
     return 0;
+}
+
+/// A bounded RCCL call's outcome as this library's status (the message is set on the CALLING thread).
+static int comm_outcome(const bounded_ns::Outcome &o, const char *what) {
+    if (o.timed_out) return fail(GPUART_HIP_ERR_TIMEOUT, o.detail);
+    if (o.rc != 0) return fail(GPUART_HIP_ERR_DEVICE, std::string(what) + ": " + (o.detail.empty() ? std::string("failed") : o.detail));
+    return 0;
+}
+
+/// Leaves the context's communicator. ncclCommDestroy waits for the communicator's outstanding work and, for a communicator of
+/// several ranks, for its proxy threads — it is one of the calls that had no bound: it runs under bounded() now.
+/// A destroy that does not return leaves the handle alone (the context forgets it) and marks the layer stuck.
+static int comm_drop(gpuart_hip_ctx *c) {
+    int r = 0;
+    if (c->comm && c->comm_owned && !bounded_ns::stuck().load()) {
+        const ncclComm_t comm = c->comm;
+        const int device = c->device;
+        const bounded_ns::Outcome o = bounded_ns::bounded("ncclCommDestroy", bounded_ns::comm_timeout_ms(), [comm, device](std::string &d) {
+            (void)hipSetDevice(device);
+            const ncclResult_t e = rccl()->CommDestroy(comm);
+            if (e != ncclSuccess) d = rccl()->GetErrorString(e);
+            return (int)e;
+        });
+        r = comm_outcome(o, "ncclCommDestroy");
+    }
+    c->comm = nullptr; c->comm_owned = false; c->comm_nranks = 0; c->comm_rank = 0; c->comm_group = 0;
+    return r;
 }
 
 /// Identity of a communicator for gpuart_hip_gather_all: process-unique serials for _comm_init_all / _comm_attach, a hash of the
@@ -1031,13 +1092,23 @@ static uint64_t next_comm_group() {
 
 int gpuart_hip_comm_init(gpuart_hip_ctx *c, int nranks, int rank, const void *id128) {
     if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(GPUART_HIP_ERR_ARG, "bad argument");
-    int r = need_rccl();
-    if (r) return r;
+    int r = comm_layer_ok();
+    if (r || (r = need_rccl())) return r;
     HIP_TRY(hipSetDevice(c->device));
-    comm_drop(c);
+    if ((r = comm_drop(c))) return r;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
-    NCCL_TRY(rccl()->CommInitRank(&c->comm, nranks, id, rank));
+    // ncclCommInitRank returns when ALL nranks ranks have called it with this id: a rank that never starts leaves the others here
+    auto made = std::make_shared<ncclComm_t>(nullptr);
+    const int device = c->device;
+    const bounded_ns::Outcome o = bounded_ns::bounded("ncclCommInitRank", bounded_ns::comm_timeout_ms(), [made, nranks, id, rank, device](std::string &d) {
+        (void)hipSetDevice(device);
+        const ncclResult_t e = rccl()->CommInitRank(made.get(), nranks, id, rank);
+        if (e != ncclSuccess) d = rccl()->GetErrorString(e);
+        return (int)e;
+    });
+    if ((r = comm_outcome(o, "ncclCommInitRank"))) return r;
+    c->comm = *made;
     c->comm_owned = true; c->comm_nranks = nranks; c->comm_rank = rank;
     uint64_t h = 1469598103934665603ull;  // FNV-1a of the 128-byte id; bit 63 set: never a serial
     for (size_t k = 0; k < sizeof id; k++) h = (h ^ ((const unsigned char *)&id)[k]) * 1099511628211ull;
@@ -1047,9 +1118,9 @@ int gpuart_hip_comm_init(gpuart_hip_ctx *c, int nranks, int rank, const void *id
 
 int gpuart_hip_comm_attach(gpuart_hip_ctx *c, void *nccl_comm, int nranks, int rank) {
     if (!c || !nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(GPUART_HIP_ERR_ARG, "bad argument");
-    int r = need_rccl();
-    if (r) return r;
-    comm_drop(c);
+    int r = comm_layer_ok();
+    if (r || (r = need_rccl())) return r;
+    if ((r = comm_drop(c))) return r;
     c->comm = (ncclComm_t)nccl_comm; c->comm_owned = false; c->comm_nranks = nranks; c->comm_rank = rank;
     c->comm_group = 0;  // the caller's communicator: which handles belong together is the caller's to know
     return 0;
@@ -1057,10 +1128,9 @@ int gpuart_hip_comm_attach(gpuart_hip_ctx *c, void *nccl_comm, int nranks, int r
 
 int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n) {
     if (!ctxs || n < 1) return fail(GPUART_HIP_ERR_ARG, "bad argument");
-    int r = need_rccl();
-    if (r) return r;
+    int r = comm_layer_ok();
+    if (r || (r = need_rccl())) return r;
     std::vector<int> devs(n);
-    std::vector<ncclComm_t> comms(n);
     for (int k = 0; k < n; k++) {
         if (!ctxs[k]) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
         devs[k] = ctxs[k]->device;
@@ -1072,12 +1142,20 @@ int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n) {
         if (!ctxs[k]->comm) continue;
         HIP_TRY(hipSetDevice(ctxs[k]->device));
         if ((r = drain(ctxs[k]))) return r;
-        comm_drop(ctxs[k]);
+        if ((r = comm_drop(ctxs[k]))) return r;
     }
-    NCCL_TRY(rccl()->CommInitAll(comms.data(), n, devs.data()));
+    // ncclCommInitAll bootstraps n ranks inside this process (one thread per rank inside RCCL, topology discovery, ring set-up):
+    // it has no timeout of its own. Under bounded(): the handles live in a block the parked thread shares.
+    auto made = std::make_shared<std::vector<ncclComm_t>>((size_t)n, nullptr);
+    const bounded_ns::Outcome o = bounded_ns::bounded("ncclCommInitAll", bounded_ns::comm_timeout_ms(), [made, devs, n](std::string &d) {
+        const ncclResult_t e = rccl()->CommInitAll(made->data(), n, devs.data());
+        if (e != ncclSuccess) d = rccl()->GetErrorString(e);
+        return (int)e;
+    });
+    if ((r = comm_outcome(o, "ncclCommInitAll"))) return r;
     const uint64_t group = next_comm_group();
     for (int k = 0; k < n; k++) {
-        ctxs[k]->comm = comms[k]; ctxs[k]->comm_owned = true; ctxs[k]->comm_nranks = n; ctxs[k]->comm_rank = k;
+        ctxs[k]->comm = (*made)[(size_t)k]; ctxs[k]->comm_owned = true; ctxs[k]->comm_nranks = n; ctxs[k]->comm_rank = k;
         ctxs[k]->comm_group = group;
     }
     return 0;
@@ -1085,7 +1163,14 @@ int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n) {
 
 int gpuart_hip_comm_destroy(gpuart_hip_ctx *c) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
-    if (c->comm) { HIP_TRY(hipSetDevice(c->device)); int r = drain(c); if (r) return r; comm_drop(c); }
+    if (c->comm) {
+        HIP_TRY(hipSetDevice(c->device));
+        // (a context whose gather gave up may still have that gather's transfers queued: the wait for them is bounded too)
+        int r = c->abandoned ? wait_stream(c, c->gather_timeout_ms, "gpuart_hip_comm_destroy: work queued before the communicator can go") : 0;
+        if (!r) r = drain(c);
+        if (r) return r;
+        return comm_drop(c);
+    }
     return 0;
 }
 
@@ -1149,24 +1234,55 @@ int check_shares(const std::vector<GatherHello> &all, int which, int root) {
     return 0;
 }
 
+/// What one rank's transfers need, by value: the closure that posts them may outlive the caller's frame (bounded.h).
+struct GatherRank {
+    int device, rank;
+    ncclComm_t comm;
+    hipStream_t stream;
+    float4 *send, *stage;
+    size_t tile_pixels;
+};
+GatherRank gather_rank(const gpuart_hip_ctx *c) { return GatherRank{c->device, c->comm_rank, c->comm, c->stream, c->d_send, c->d_stage, c->plan.tile_pixels}; }
+
 /// One rank's transfers, between ncclGroupStart and ncclGroupEnd; nothing in here can fail for a reason of this rank alone
 /// (buffers exist, shares are validated): a peer posts its send, the root its receives into the staging area.
-ncclResult_t gather_post(gpuart_hip_ctx *c, int root, const std::vector<GatherHello> &all) {
-    const int n = (int)all.size(), me = c->comm_rank;
+ncclResult_t gather_post(const GatherRank &g, int root, const std::vector<GatherHello> &all) {
+    const int n = (int)all.size(), me = g.rank;
     if (me != root) {
-        if (!c->plan.tile_pixels) return ncclSuccess;  // an empty share (more ranks than bands)
-        return rccl()->Send(c->d_send, c->plan.tile_pixels * 4, ncclFloat, root, c->comm, c->stream);
+        if (!g.tile_pixels) return ncclSuccess;  // an empty share (more ranks than bands)
+        return rccl()->Send(g.send, g.tile_pixels * 4, ncclFloat, root, g.comm, g.stream);
     }
     size_t off = 0;
     for (int k = 0; k < n; k++) {
         const size_t cnt = (size_t)all[k].g.tw * all[k].g.th;
         if (k != me && cnt) {
-            const ncclResult_t e = rccl()->Recv(c->d_stage + off, cnt * 4, ncclFloat, k, c->comm, c->stream);
+            const ncclResult_t e = rccl()->Recv(g.stage + off, cnt * 4, ncclFloat, k, g.comm, g.stream);
             if (e != ncclSuccess) return e;
         }
         off += cnt;
     }
     return ncclSuccess;
+}
+
+/// The group of transfers of the given ranks of this process (one for gpuart_hip_gather, all of them for _gather_all), posted
+/// from ONE thread — RCCL's group state is per thread — under bounded(): ncclGroupEnd connects peers that have not talked before
+/// and returns when that is done, i.e. when every peer has reached its own group; it has no timeout of its own.
+int gather_transfers(const std::vector<GatherRank> &ranks, int root, const std::vector<GatherHello> &all) {
+    const bounded_ns::Outcome o = bounded_ns::bounded("ncclGroupStart .. ncclGroupEnd (the gather's send / recv group)", bounded_ns::comm_timeout_ms(),
+                                                      [ranks, root, all](std::string &d) {
+        ncclResult_t e = rccl()->GroupStart();
+        if (e != ncclSuccess) { d = std::string("ncclGroupStart: ") + rccl()->GetErrorString(e); return (int)e; }
+        ncclResult_t pe = ncclSuccess;
+        for (size_t k = 0; k < ranks.size() && pe == ncclSuccess; k++) {
+            if (hipSetDevice(ranks[k].device) != hipSuccess) { pe = ncclUnhandledCudaError; break; }
+            pe = gather_post(ranks[k], root, all);
+        }
+        const ncclResult_t ge = rccl()->GroupEnd();
+        if (pe != ncclSuccess) { d = std::string("posting the transfers: ") + rccl()->GetErrorString(pe); return (int)pe; }
+        if (ge != ncclSuccess) { d = std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge); return (int)ge; }
+        return 0;
+    });
+    return comm_outcome(o, "gather");
 }
 
 /// After the group: the root scatters every share's rows into the full frame (its own straight from its send buffer).
@@ -1183,19 +1299,6 @@ int gather_place(gpuart_hip_ctx *c, const std::vector<GatherHello> &all, float4 
     return 0;
 }
 
-/// Waits for the context's primary stream, but not for ever: a peer that never arrives must not hang this process.
-int wait_stream(gpuart_hip_ctx *c, uint32_t timeout_ms, const char *what) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t e = hipStreamQuery(c->stream);
-        if (e == hipSuccess) return 0;
-        if (e != hipErrorNotReady) return fail(GPUART_HIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
-        if (timeout_ms && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms))
-            return fail(GPUART_HIP_ERR_TIMEOUT, std::string(what) + ": not complete after " + std::to_string(timeout_ms) +
-                        " ms (rank " + std::to_string(c->comm_rank) + " of " + std::to_string(c->comm_nranks) + "; a peer has not joined the collective)");
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
-    }
-}
 }  // namespace
 }  // extern "C++"
 
@@ -1271,21 +1374,27 @@ int gpuart_hip_gather(gpuart_hip_ctx *c, int which, float divide_by, int root, v
     //    rank can block, and it is bounded —, and a call that gives up leaves no queued copy pointing at its own stack or heap.
     GatherHello *d = (GatherHello *)c->d_hello, *hh = (GatherHello *)c->h_hello;
     hh[0] = own;
+    int r;
+    if ((r = comm_layer_ok())) return r;
     HIP_TRY(hipMemcpyAsync(d, hh, sizeof own, hipMemcpyHostToDevice, c->stream));
-    NCCL_TRY(rccl()->AllGather(d, d + 1, sizeof own / 4, ncclUint32, c->comm, c->stream));
+    {   // (enqueueing a collective may itself wait — the first use of a channel —: under bounded(), bounded.h)
+        const GatherRank me = gather_rank(c);
+        const bounded_ns::Outcome o = bounded_ns::bounded("ncclAllGather (share exchange)", bounded_ns::comm_timeout_ms(), [me, d](std::string &dt) {
+            (void)hipSetDevice(me.device);
+            const ncclResult_t e = rccl()->AllGather(d, d + 1, sizeof(GatherHello) / 4, ncclUint32, me.comm, me.stream);
+            if (e != ncclSuccess) dt = rccl()->GetErrorString(e);
+            return (int)e;
+        });
+        if ((r = comm_outcome(o, "ncclAllGather"))) return r;
+    }
     HIP_TRY(hipMemcpyAsync(hh + 1, d + 1, (size_t)n * sizeof own, hipMemcpyDeviceToHost, c->stream));
-    int r = wait_stream(c, c->gather_timeout_ms, "gather: exchange of the shares");
-    if (r) return r;
+    if ((r = wait_stream(c, c->gather_timeout_ms, "gather: exchange of the shares"))) return r;
     if (mine) return fail(mine, my_error);
     std::vector<GatherHello> all(hh + 1, hh + 1 + n);
     // 3. the same table on every rank: the same verdict on every rank
     if ((r = check_shares(all, which, root))) return r;
     // 4. the transfers
-    NCCL_TRY(rccl()->GroupStart());
-    const ncclResult_t pe = gather_post(c, root, all);
-    const ncclResult_t ge = rccl()->GroupEnd();
-    if (pe != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("gather: posting the transfers: ") + rccl()->GetErrorString(pe));
-    if (ge != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
+    if ((r = gather_transfers({gather_rank(c)}, root, all))) return r;
     if (c->comm_rank == root) return gather_place(c, all, (float4 *)full_frame_device);
     return 0;
 }
@@ -1304,15 +1413,10 @@ int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float d
         if ((r = gather_prepare(ctxs[k], which, divide_by, root, all[(size_t)k]))) return r;
     }
     if ((r = check_shares(all, which, root))) return r;
-    NCCL_TRY(rccl()->GroupStart());
-    ncclResult_t pe = ncclSuccess;
-    for (int k = 0; k < n && pe == ncclSuccess; k++) {
-        if (hipSetDevice(ctxs[k]->device) != hipSuccess) { pe = ncclUnhandledCudaError; break; }
-        pe = gather_post(ctxs[k], root, all);
-    }
-    const ncclResult_t ge = rccl()->GroupEnd();
-    if (pe != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("gather: posting the transfers: ") + rccl()->GetErrorString(pe));
-    if (ge != ncclSuccess) return fail(GPUART_HIP_ERR_DEVICE, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
+    if ((r = comm_layer_ok())) return r;
+    std::vector<GatherRank> ranks;
+    for (int k = 0; k < n; k++) ranks.push_back(gather_rank(ctxs[k]));
+    if ((r = gather_transfers(ranks, root, all))) return r;
     HIP_TRY(hipSetDevice(ctxs[root]->device));
     return gather_place(ctxs[root], all, (float4 *)full_frame_device);
 }
@@ -1326,9 +1430,12 @@ int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, fl
     if (r) return r;
     if ((r = gpuart_hip_gather_all(ctxs, n, which, divide_by, root, c->d_scratch))) return r;
     HIP_TRY(hipSetDevice(c->device));
+    // The copy is queued behind the root's receives: waiting for it is waiting for every peer's rows. Bounded like the exchange of
+    // gpuart_hip_gather (this wait was a plain hipStreamSynchronize until round 5 — one of the three unbounded waits on the path
+    // of the gpuart_cli child that once did not end, profiles/r05/stall_path.txt). A caller whose wait runs out must keep
+    // full_frame_host alive until the process ends (the queued copy may still land in it): gpuart_cli and bench.py exit.
     HIP_TRY(hipMemcpyAsync(full_frame_host, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return wait_stream(c, c->gather_timeout_ms, "gather: the peers' rows and the read-back of the frame");
 }
 
 // ---- uploader hook: what gpuart_hip_upload_bvh decides about a tree, without a device (include/gpuart_hip.h) ----------
@@ -1553,6 +1660,23 @@ int gpuart_hip_test_sort_tiles(gpuart_hip_ctx *c, const uint32_t *cost, size_t n
     HIP_TRY(e);
     return 0;
 }
+// ---- phase watchdog and the bounded-call mechanism (bounded.h; pure host code) ----------------------------------------------
+int gpuart_hip_phase_begin(const char *name, uint32_t timeout_ms) { return bounded_ns::phase_begin(name, timeout_ms); }
+int gpuart_hip_phase_end(void) { return bounded_ns::phase_end(); }
+int gpuart_hip_comm_stuck(void) { return bounded_ns::stuck().load() ? 1 : 0; }
+int gpuart_hip_test_bounded_call(uint32_t hold_ms, uint32_t timeout_ms, int mark_stuck) {
+    // (the helper's own `stuck` mark is global: the hook restores it unless the test wants to see the layer refuse its entry points)
+    const bool was = bounded_ns::stuck().load();
+    const bounded_ns::Outcome o = bounded_ns::bounded("gpuart_hip_test_bounded_call", timeout_ms, [hold_ms](std::string &d) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(hold_ms));
+        d = "held for " + std::to_string(hold_ms) + " ms";
+        return 0;
+    });
+    if (!mark_stuck && !was) bounded_ns::stuck().store(false);
+    if (o.timed_out) return fail(GPUART_HIP_ERR_TIMEOUT, o.detail);
+    return o.rc;
+}
+
 int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
     if (!c || ms > 5000) return fail(GPUART_HIP_ERR_ARG, "bad argument (at most 5000 ms)");
     HIP_TRY(hipSetDevice(c->device));

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "renderer.h"
 #include "scenes.h"
 
@@ -134,6 +136,16 @@ int main(int argc, char **argv) {
             std::vector<gpuart::Renderer *> ranks;
             for (auto &q : rs) ranks.push_back(q.get());
             ok = gpuart::Renderer::GatherRadiance(ranks.data(), (int)gpus, 0, true, img.data());
+            // The communicator goes in a phase of its own, not in the destructors at exit. A read-out that gave up (a bounded wait
+            // of the library ran out: a message above says which) leaves streams and possibly a parked RCCL thread behind:
+            // nothing of that is waited for again — no destructors, no atexit handlers.
+            if (ok) ok = gpuart::Renderer::ReleaseCommunicator(ranks.data(), (int)gpus);
+            if (!ok) {
+                std::cerr << "gpuart_cli: the multi-GPU read-out failed" << (gpuart_hip_comm_stuck() ? " (an RCCL call never returned)" : "")
+                          << "; ending without unwinding." << std::endl;
+                fflush(nullptr);
+                _exit(1);
+            }
         } else
             ok = r.ReadRadiance(img.data(), true);
     }

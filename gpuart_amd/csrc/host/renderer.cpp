@@ -117,6 +117,16 @@ bool Renderer::SetShare(int rank, int nranks) {
     return SetInterleavedTile(g.x0, g.y0, g.tw, g.th, g.band_rows, g.band_stride);
 }
 
+/// Bound of one phase of the multi-GPU read-out for the library's watchdog (gpuart_hip_phase_begin): GPUART_PHASE_TIMEOUT_MS,
+/// default 300 s — above the library's own bounds (GPUART_HIP_COMM_TIMEOUT_MS 120 s, GPUART_HIP_GATHER_TIMEOUT_MS 60 s), which
+/// come back with an error first; the watchdog is for whatever those do not wrap.
+static uint32_t PhaseTimeoutMs() {
+    const char *v = getenv("GPUART_PHASE_TIMEOUT_MS");
+    if (!v) return 300000u;
+    const long x = strtol(v, nullptr, 10);
+    return x <= 0 ? 0u : (uint32_t)x;
+}
+
 bool Renderer::GatherRadiance(Renderer *const *ranks, int n, int root, bool normalized, float *fullFrame) {
     if (!ranks || n < 1 || root < 0 || root >= n || !fullFrame) return false;
     std::vector<gpuart_hip_ctx *> ctxs((size_t)n);
@@ -128,12 +138,32 @@ bool Renderer::GatherRadiance(Renderer *const *ranks, int n, int root, bool norm
     const float div = normalized && r0.PathTracing.numPathsRendered ? (float)r0.PathTracing.numPathsRendered : 1.0f;
     // One communicator per set of renderers, kept by the contexts themselves. Whether these contexts are (still) the ranks
     // 0..n-1 of one is the library's to say: it answers GPUART_HIP_ERR_NO_COMM before anything is transferred, then one is made.
+    // Every step that waits for RCCL or for the other GPUs is a named phase (a line on stderr before and after, and the
+    // library's watchdog behind it): a read-out that stalls says where.
+    const uint32_t bound = PhaseTimeoutMs();
+    gpuart_hip_phase_begin("frame gather (gpuart_hip_gather_all_read)", bound);
     int rc = gpuart_hip_gather_all_read(ctxs.data(), n, 1, div, root, fullFrame);
+    gpuart_hip_phase_end();
     if (rc == GPUART_HIP_ERR_NO_COMM) {
-        if (!r0.Check(gpuart_hip_comm_init_all(ctxs.data(), n), "creating the RCCL communicator")) return false;
+        gpuart_hip_phase_begin("communicator init (gpuart_hip_comm_init_all = ncclCommInitAll)", bound);
+        const bool made = r0.Check(gpuart_hip_comm_init_all(ctxs.data(), n), "creating the RCCL communicator");
+        gpuart_hip_phase_end();
+        if (!made) return false;
+        gpuart_hip_phase_begin("frame gather (gpuart_hip_gather_all_read)", bound);
         rc = gpuart_hip_gather_all_read(ctxs.data(), n, 1, div, root, fullFrame);
+        gpuart_hip_phase_end();
     }
     return r0.Check(rc, "gathering the frame");
+}
+
+bool Renderer::ReleaseCommunicator(Renderer *const *ranks, int n) {
+    if (!ranks || n < 1) return false;
+    bool ok = true;
+    gpuart_hip_phase_begin("communicator destroy (gpuart_hip_comm_destroy = ncclCommDestroy)", PhaseTimeoutMs());
+    for (int k = 0; k < n; k++)
+        if (ranks[k] && ranks[k]->Backend) ok = ranks[k]->Check(gpuart_hip_comm_destroy(ranks[k]->Backend), "destroying the RCCL communicator") && ok;
+    gpuart_hip_phase_end();
+    return ok;
 }
 
 bool Renderer::SetCamera(const Camera &cam) {

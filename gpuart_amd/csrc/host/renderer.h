@@ -101,6 +101,10 @@ public:
     /// (gpuart_hip_gather_all), normalized = divided by the paths rendered. Replaces the normalise-to-display step of the
     /// reference (src/renderer.cpp:601-616) for a frame that lives on several GPUs.
     static bool GatherRadiance(Renderer *const *ranks, int n, int root, bool normalized, float *fullFrame);
+    /// Gives the communicator GatherRadiance made back (ncclCommDestroy per rank) as a named, watched phase of its own, instead
+    /// of leaving it to the renderers' destructors at exit. False if a rank's destroy failed or did not return within its bound
+    /// (gpuart_hip_comm_stuck() tells which): the caller should then end the process without unwinding.
+    static bool ReleaseCommunicator(Renderer *const *ranks, int n);
     unsigned GetNumPathsRendered() const { return PathTracing.numPathsRendered; }
     /// Progressive-render checkpoint: accumulator + pass counters + RNG state of this tile.
     /// After LoadCheckpoint the following passes are bit-identical to those of the uninterrupted run. The

@@ -34,7 +34,7 @@ typedef enum gpuart_hip_status {
     GPUART_HIP_ERR_ARG = -1,      /* bad argument / call order (e.g. render before upload) */
     GPUART_HIP_ERR_DEVICE = -2,   /* a HIP runtime call failed */
     GPUART_HIP_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
-    GPUART_HIP_ERR_TIMEOUT = -4,  /* a bounded wait ran out (gpuart_hip_wait, the share exchange of gpuart_hip_gather): a peer is missing */
+    GPUART_HIP_ERR_TIMEOUT = -4,  /* a bounded wait ran out (gpuart_hip_wait, the waits of the gather, an RCCL call that did not return): a peer is missing */
     GPUART_HIP_ERR_NO_COMM = -5   /* the contexts are not (or no longer) the ranks of one communicator: make one and call again */
 } gpuart_hip_status;
 
@@ -173,11 +173,37 @@ int gpuart_hip_comm_info(gpuart_hip_ctx *ctx, int *nranks, int *rank);
  * return an error rather than leaving its peers blocked in a receive. The shares must be full-width rows covering every frame
  * row exactly once (gpuart_hip_share_of_rank; a rank beyond the number of bands holds an empty share and sends nothing). The
  * host-side wait for the share exchange is bounded (GPUART_HIP_GATHER_TIMEOUT_MS, default 60 000, 0 = unbounded):
- * GPUART_HIP_ERR_TIMEOUT means a peer never entered the collective. */
+ * GPUART_HIP_ERR_TIMEOUT means a peer never entered the collective.
+ * EVERY host-side wait of this section is bounded (round 5; until then only the share exchange of gpuart_hip_gather was):
+ *   - waits on the context's stream — the share exchange, the read-back of gpuart_hip_gather_all_read, gpuart_hip_comm_destroy
+ *     and gpuart_hip_destroy of a context whose gather gave up — by GPUART_HIP_GATHER_TIMEOUT_MS;
+ *   - RCCL calls that return only when peers or RCCL's bootstrap play along — ncclCommInitRank / ncclCommInitAll, the
+ *     ncclAllGather enqueue, ncclGroupStart..ncclGroupEnd of the transfers, ncclCommDestroy — by GPUART_HIP_COMM_TIMEOUT_MS
+ *     (default 120 000, 0 = unbounded): they run on a helper thread; when the bound runs out the call returns
+ *     GPUART_HIP_ERR_TIMEOUT naming the RCCL call, the helper stays parked in it, and from then on every entry point of this
+ *     section fails at once with GPUART_HIP_ERR_TIMEOUT (gpuart_hip_comm_stuck() == 1): end the process with _exit.
+ * GPUART_HIP_RCCL_LIBRARY names the RCCL to load instead of the system's librccl.so.1. */
 int gpuart_hip_gather(gpuart_hip_ctx *ctx, int which, float divide_by, int root, void *full_frame_device);
 int gpuart_hip_gather_all(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, void *full_frame_device);
 /* gpuart_hip_gather_all into host memory (W*H*4 floats): the frame is assembled on the root's device, then read back. */
 int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, float divide_by, int root, float *full_frame_host);
+
+/* 1 once an RCCL call of this process has outlived GPUART_HIP_COMM_TIMEOUT_MS (see above), else 0. */
+int gpuart_hip_comm_stuck(void);
+
+/* Phase watchdog (pure host code; no reference counterpart — the reference's render loop, src/main.cpp:549-599, has nothing
+ * that waits for another process). The caller names what it is about to do and how long that may take; gpuart_hip_phase_end
+ * disarms. A watcher thread that sees the phase outlive its bound writes the phase, how long it has run and the most recent
+ * error messages of libgpuart_hip.so of ALL threads to stderr and ends the process with _exit(86) — no unwinding, nothing is
+ * re-executed. One phase at a time (a second begin replaces the first). timeout_ms 0: only the phase lines. Every begin / end
+ * writes one line to stderr unless GPUART_HIP_PHASE_LOG=0. gpuart_cli --gpus N and the ranks of bench.py bracket communicator
+ * creation, the gather and communicator destruction with it. */
+int gpuart_hip_phase_begin(const char *name, uint32_t timeout_ms);
+int gpuart_hip_phase_end(void);
+/* Test hook of the mechanism behind the bounded RCCL calls (no device needed): a call that holds for hold_ms under a bound of
+ * timeout_ms (0: inline, unbounded). 0 if it returned in time, GPUART_HIP_ERR_TIMEOUT otherwise; mark_stuck != 0 leaves the
+ * communicator layer marked out of service as a real timeout does. */
+int gpuart_hip_test_bounded_call(uint32_t hold_ms, uint32_t timeout_ms, int mark_stuck);
 
 /* glFlush() equivalent. gpuart_hip_pt_pass may only *collect* a pass: passes with identical parameters are launched
  * together as one run of the pipeline (path slot = pixel x passes of the run + pass, up to 16M paths, so that the persistent

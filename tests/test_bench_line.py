@@ -76,22 +76,29 @@ def test_roofline_block_from_stubbed_counters(tmp_path):
     assert trace["k_trace"] == (2, 3.0 * passes) and trace["k_gen"][0] == 1
     ms = 0.8
     roof = BL.assemble_roofline(ms, passes, prof, trace, executed={"nodes": 1.6e8, "steps": 0.79e8, "algorithmic_bytes": 8.0e9},
-                                reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1))
-    # the contract's keys
+                                reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1), passes_timed=100)
+    # the contract's keys, and the contract's arithmetic: 200 launches in 100 timed passes = 2 per pass, 8e9 algorithmic bytes per pass = 4e9 per
+    # launch, 2.0 ms per launch on average -> 2000 GB/s of 8000; traffic = the dominant kernel's own PMC bytes / its 2 profiled launches
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["per_launch"]["launches_per_pass"] == pytest.approx(2.0) and roof["per_launch"]["algorithmic_bytes"] == pytest.approx(4.0e9)
+    assert roof["per_launch"]["avg_ms"] == pytest.approx(2.0)
+    assert roof["achieved"] == pytest.approx(2000.0) and roof["frac"] == pytest.approx(0.25)
+    assert roof["traffic"] == pytest.approx((2 * 100000 + 50000) * 1024.0 * passes / 2)
     # issue slots: (5e8 + 5e7 + 1e7) instructions per pass / 0.8 ms = 700 G/s of 1228.8
     vi = roof["valu_issue"]
     assert vi["instr_per_pass"] == pytest.approx(5.6e8) and vi["achieved"] == pytest.approx(700.0) and vi["frac"] == pytest.approx(700.0 / 1228.8, abs=1e-4)
     # lane utilisation is instruction-weighted over ALL kernels: (5e8*.6 + 5e7*.9 + 1e7) / 5.6e8
     lu = (5e8 * 0.6 + 5e7 * 0.9 + 1e7) / 5.6e8
     assert vi["lane_util"] == pytest.approx(lu, abs=1e-4)
-    # the headline: useful lane slots = issue share x lane utilisation, and achieved / peak says the same
-    assert roof["bound"] == "valu_lanes" and roof["frac"] == pytest.approx(vi["frac"] * lu, abs=2e-4)
-    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=2e-4) and 0 < roof["frac"] < vi["frac"] < 1
+    # useful lane slots (the top-level figure of rounds 3-4, now a block of its own) = issue share x lane utilisation, and achieved / peak says the same
+    ls = roof["lane_slots"]
+    assert ls["frac"] == pytest.approx(vi["frac"] * lu, abs=2e-4)
+    assert ls["frac"] == pytest.approx(ls["achieved"] / ls["peak"], abs=2e-4) and 0 < ls["frac"] < vi["frac"] < 1
     # HBM: 2 x FETCH + WRITE, KB -> bytes, per pass of the PROFILED shape; fractions of the 8 TB/s peak over ms_per_step
     traffic = (2 * 400000 + 300000) * 1024.0
-    assert roof["traffic"] == pytest.approx(traffic) and roof["hbm"]["traffic_frac"] == pytest.approx(traffic / 0.8e-3 / 8e12, abs=1e-4)
+    assert roof["hbm"]["traffic_bytes_per_pass"] == pytest.approx(traffic) and roof["hbm"]["traffic_frac"] == pytest.approx(traffic / 0.8e-3 / 8e12, abs=1e-4)
     assert roof["hbm"]["traffic_over_algorithmic"] == pytest.approx(traffic / 8.0e9, abs=1e-3)
     # the algorithmic bytes against HBM (> 1: cache-resident tree) and against the guide's L2 rate (< 1)
     assert roof["hbm"]["algorithmic_rate_over_peak"] == pytest.approx(8.0e9 / 0.8e-3 / 8e12, abs=1e-3) and roof["hbm"]["algorithmic_rate_over_peak"] > 1
@@ -113,8 +120,44 @@ def test_roofline_block_from_stubbed_counters(tmp_path):
     assert roof["kernel_avg_ms"] == pytest.approx(2.0) and roof["kernel_concurrency"] == pytest.approx(4.0)
     # a different number of profiled passes changes every per-pass figure: the denominator is the children's own pass count
     half = BL.assemble_roofline(ms, passes // 2, prof, trace, executed={"nodes": 1.6e8, "steps": 0.79e8, "algorithmic_bytes": 8.0e9},
-                                reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1))
-    assert half["valu_issue"]["instr_per_pass"] == pytest.approx(2 * 5.6e8) and half["traffic"] == pytest.approx(2 * traffic)
+                                reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1), passes_timed=100)
+    assert half["valu_issue"]["instr_per_pass"] == pytest.approx(2 * 5.6e8) and half["hbm"]["traffic_bytes_per_pass"] == pytest.approx(2 * traffic)
+    assert half["traffic"] == pytest.approx(roof["traffic"])  # per LAUNCH of the dominant kernel: its own launch count divides it, not the pass count
+
+
+def test_every_ratio_divides_like_by_like(tmp_path):
+    """Rounds 2-4 printed node_visits.frac = BOX TESTS per second / a peak in NODE VISITS per second (two box tests per visit): 0.87-0.90 that
+    were 0.44-0.45. Every block with achieved / peak / frac now names the quantity both are counted in (BL.RATIO_QUANTITIES), and each numerator
+    is pinned here to the input it must come from — by feeding inputs in which the candidates differ by factors no rounding explains."""
+    passes = 10
+    _write_counters(str(tmp_path / "valu"), [(KT, "SQ_INSTS_VALU", 3e8 * passes), (KT, "SQ_ACTIVE_INST_VALU", 12e8 * passes), (KT, "SQ_THREAD_CYCLES_VALU", 12e8 * passes * 32)])
+    _write_counters(str(tmp_path / "tcp"), [(KT, "TCP_TOTAL_CACHE_ACCESSES_sum", 2e8 * passes), (KT, "TCP_TOTAL_ACCESSES_sum", 7e8 * passes)])
+    _write_counters(str(tmp_path / "fetch"), [(KT, "FETCH_SIZE", 1000 * passes)])
+    _write_trace(str(tmp_path / "trace"), [(KT, 0, 1_000_000)] * 5)
+    prof = {t: BL.read_counters(str(tmp_path / t)) for t in ("valu", "tcp", "fetch")}
+    ex = {"nodes": 7.0e8, "steps": 1.0e8, "algorithmic_bytes": 3.0e9}     # 7 box tests per visit: nothing real, so that a mix-up cannot hide
+    roof = BL.assemble_roofline(1.0, passes, prof, BL.read_kernel_trace(str(tmp_path / "trace")), executed=ex, reference={"nodes": 9e8, "algorithmic_bytes": 5e9},
+                                kernel_events=(30.0, 20, 0.01), passes_timed=10)
+    blocks = {"": roof, "lane_slots": roof["lane_slots"], "valu_issue": roof["valu_issue"], "l1_accesses": roof["l1_accesses"], "node_visits": roof["node_visits"]}
+    assert set(blocks) == set(BL.RATIO_QUANTITIES)
+    for name, b in blocks.items():
+        assert b["quantity"] == BL.RATIO_QUANTITIES[name], name
+        assert b["frac"] == pytest.approx(b["achieved"] / b["peak"], rel=2e-3), name
+    # no other block of the object carries a frac without being listed
+    extra = [k for k, v in roof.items() if isinstance(v, dict) and "frac" in v and "peak" in v and k not in blocks]
+    assert extra == ["hbm"] or extra == [], extra       # (hbm: rates over named peaks, each key says which: *_over_peak, *_over_l2_peak, traffic_frac)
+    s = 1.0e-3
+    assert roof["node_visits"]["achieved"] == pytest.approx(ex["steps"] / s / 1e9, rel=1e-3)            # visits, NOT box tests
+    assert roof["node_visits"]["achieved"] != pytest.approx(ex["nodes"] / s / 1e9, rel=0.5)
+    assert "visits" in roof["node_visits"]["quantity"] and "visits" in roof["node_visits"]["unit"]
+    assert roof["node_visits"]["box_tests_per_s"] == pytest.approx(ex["nodes"] / s / 1e9, rel=1e-3)      # kept beside it, under its own name
+    assert roof["valu_issue"]["achieved"] == pytest.approx(3e8 / s / 1e9, rel=1e-3)                      # instructions, not active cycles (4x) nor thread cycles
+    assert roof["lane_slots"]["achieved"] == pytest.approx(3e8 * 64 * 0.5 / s / 1e12, rel=1e-3)          # instructions x 64 x lane utilisation (32 of 64)
+    assert roof["l1_accesses"]["achieved"] == pytest.approx(2e8 / s / 1e9, rel=1e-3)                     # cache accesses after coalescing, not requests (3.5x)
+    # top level: bytes of ONE launch / duration of ONE launch — 20 launches in 10 passes, 30 ms summed
+    assert roof["achieved"] == pytest.approx((3.0e9 / 2) / 1.5e-3 / 1e9, rel=1e-3)
+    assert roof["achieved"] != pytest.approx(3.0e9 / s / 1e9, rel=0.3)                                   # not bytes per PASS over wall time per pass
+    assert roof["traffic"] == pytest.approx(2 * 1000 * passes * 1024.0 / 5)                               # FETCH doubled, KB, / the kernel's 5 profiled launches
 
 
 def test_roofline_block_without_counters_keeps_the_contract_keys():
@@ -122,7 +165,7 @@ def test_roofline_block_without_counters_keeps_the_contract_keys():
                                 kernel_events=(0.0, 0, 0.0))
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof
-    assert roof["frac"] is None and roof["traffic"] is None and roof["kernels"] is None and roof["hbm"]["algorithmic_rate_over_peak"] == pytest.approx(0.125)
+    assert roof["bound"] == "hbm" and roof["frac"] is None and roof["lane_slots"]["frac"] is None and roof["traffic"] is None and roof["kernels"] is None and roof["hbm"]["algorithmic_rate_over_peak"] == pytest.approx(0.125)
 
 
 def test_bench_py_uses_the_shared_definitions():
@@ -136,7 +179,8 @@ def _lines():
     out = []
     for rnd, names in (("r03", ["bench.json", "bench_driver_config.json", "bench_dragon871k.json", "bench_cfg2.json", "bench_4k.json"]),
                        ("r04", sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r04", "bench*.json"))
-                              if "steps1" not in p))):  # (bench_steps1.json: --no-profile --no-cpu-baseline, one pass alone: no roofline counters)
+                              if "steps1" not in p)),  # (bench_steps1.json: --no-profile --no-cpu-baseline, one pass alone: no roofline counters)
+                       ("r05", sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r05", "bench*.json")) if "steps1" not in p))):
         out += [(rnd, n) for n in names]
     return out
 
@@ -161,9 +205,18 @@ def test_committed_bench_lines_keep_the_contract(rnd, name):
     assert r["traffic"] > 0 and 0 < r["l2"]["hit_rate"] < 1 and 0 < r["hbm"]["traffic_frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and "sample" in c
-    if rnd >= "r04":  # this round's additions
+    if rnd >= "r05":  # the top level follows the contract's formula; the lane-slot share is a block beside it; the timed frames are checked in-run
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and d["frames_verified"] is True
+        pl = r["per_launch"]
+        assert abs(r["achieved"] - pl["algorithmic_bytes"] / (pl["avg_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+        ls = r["lane_slots"]
+        assert abs(ls["frac"] - r["valu_issue"]["frac"] * r["valu_issue"]["lane_util"]) < 2e-3
+        for name in BL.RATIO_QUANTITIES:
+            assert (r if name == "" else r[name])["quantity"] == BL.RATIO_QUANTITIES[name]
+    if rnd >= "r04":  # round 4's additions
         assert d["metric_version"] == 3 and "value_definition" in d
-        assert r["bound"] == "valu_lanes" and abs(r["frac"] - r["valu_issue"]["frac"] * r["valu_issue"]["lane_util"]) < 2e-3
+        if rnd == "r04":
+            assert r["bound"] == "valu_lanes" and abs(r["frac"] - r["valu_issue"]["frac"] * r["valu_issue"]["lane_util"]) < 2e-3
         ws = r["k_trace_wave_states"]
         assert ws and 0.9 < ws["executing"] + ws["s_waitcnt"] + ws["issue_wait"] < 1.1
         fams = [k["kernel"] for k in r["kernels"]]

@@ -412,6 +412,78 @@ __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, ui
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+
+// ---- round 5: fewer requests per node visit. A node box is the union of its two children's boxes (reference src/bvh.cpp:41-72), so for
+//      each of the 6 axis-sides at least one child's plane IS the parent's: of a record's 12 child planes only 6 are new. k_step32 is the
+//      traversal step on a 32-byte record {6 new planes, 2 refs with 3 selector bits each}: the lane carries the current node's six plane
+//      PARAMETERS k = (plane - o) * rdiv (what the quick box test consumes), computes the six new ones (12 VALU instead of 24) and deals
+//      them out with 12 selects. A child that is STACKED needs its own six parameters again when it is popped: POP_PCT per cent of the
+//      lanes (data-dependent, divergent) first fetch a 32-byte box of their own from a second array and recompute the six parameters,
+//      as a pop would. MODE 0: fetch + decode + two quick box tests; 1: fetch only.
+template <int MODE, int POP_PCT>
+__global__ void __launch_bounds__(64) k_step32(const float4 *__restrict__ recs, const float4 *__restrict__ boxes, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
+    using namespace gd;
+    uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
+    const uint32_t zero = g_zero;
+    Ray r;
+    r.o = f3(0.1f + threadIdx.x * 0.01f, -3.0f, 1.0f);
+    r.d = f3(0.02f * threadIdx.x - 0.6f, 1.0f, -0.1f);
+    const F3 rdiv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    const float cs = gq_ray_slack(gq_slack_of_tree(2.0f), r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
+    float kp[6] = {-1.0f, 2.0f, -0.5f, 1.5f, -0.25f, 3.0f};  // the current node's plane parameters (x lo, x hi, y lo, y hi, z lo, z hi)
+    float acc = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        uint32_t h = 0;
+        if (POP_PCT > 0 && ((idx >> 9) % 100u) < (uint32_t)POP_PCT) {  // this lane's node came off the stack: its own box, fetched; six parameters
+            const float4 *b = boxes + 2 * (size_t)((idx >> 3) & mask);
+            float4 lo = b[0], hi = b[1];
+            asm volatile("" : "+v"(lo.w), "+v"(hi.w));
+            kp[0] = (lo.x * 1e-9f - r.o.x) * rdiv.x; kp[1] = (hi.x * 1e-9f + 1 - r.o.x) * rdiv.x;
+            kp[2] = (lo.y * 1e-9f - r.o.y) * rdiv.y; kp[3] = (hi.y * 1e-9f + 1 - r.o.y) * rdiv.y;
+            kp[4] = (lo.z * 1e-9f - r.o.z) * rdiv.z; kp[5] = (hi.z * 1e-9f + 1 - r.o.z) * rdiv.z;
+            h += __float_as_uint(lo.w) + __float_as_uint(hi.w);
+        }
+        const float4 *p = recs + 2 * (size_t)(idx & mask);
+        float4 a = p[0], b = p[1];
+        asm volatile("" : "+v"(a.w), "+v"(b.w));
+        const uint32_t ra = __float_as_uint(a.w), rb = __float_as_uint(b.w);
+        h += ra + rb;
+        if (MODE == 0) {
+            // six new parameters (the planes are random bits scaled into a sane range: the arithmetic is what matters)
+            const float kn[6] = {(a.x * 1e-9f - r.o.x) * rdiv.x, (a.y * 1e-9f + 1 - r.o.x) * rdiv.x, (a.z * 1e-9f - r.o.y) * rdiv.y,
+                                 (b.x * 1e-9f + 1 - r.o.y) * rdiv.y, (b.y * 1e-9f - r.o.z) * rdiv.z, (b.z * 1e-9f + 1 - r.o.z) * rdiv.z};
+            // selector bit j (bits 25..27 of the two refs): the LOWER child takes the new plane of axis-side j, the upper one the parent's; clear: the other way round
+            const uint32_t sel = ((ra >> 25) & 7u) | (((rb >> 25) & 7u) << 3);
+            float kl[6], kh[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool s = (sel >> j) & 1u;
+                kl[j] = s ? kn[j] : kp[j];
+                kh[j] = s ? kp[j] : kn[j];
+            }
+            float e0, e1;
+            bool h0, h1;
+            const bool s0 = gq_box(kl[0], kl[1], kl[2], kl[3], kl[4], kl[5], fabsf(rdiv.x), fabsf(rdiv.y), fabsf(rdiv.z), cs, e0, h0);
+            const bool s1 = gq_box(kh[0], kh[1], kh[2], kh[3], kh[4], kh[5], fabsf(rdiv.x), fabsf(rdiv.y), fabsf(rdiv.z), cs, e1, h1);
+            acc += (s0 & s1) ? 0.0f : 3.0f;
+            acc += (h0 ? e0 : 1.0f) + (h1 ? e1 : 2.0f);
+            // descend into the nearer child: ITS parameters become the carried ones (the product does exactly this)
+            const bool near_lo = !(e1 < e0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) kp[j] = near_lo ? kl[j] : kh[j];
+            asm volatile("" : "+v"(kp[0]), "+v"(kp[1]), "+v"(kp[2]), "+v"(kp[3]), "+v"(kp[4]), "+v"(kp[5]), "+v"(acc));
+            h += __float_as_uint(acc);  // the next address waits for the tests, as a traversal step's does
+        } else {
+            acc += ((a.x + a.y) + (a.z + b.x)) + (b.y + b.z);
+        }
+        idx = idx * 1664525u + 1013904223u + (h & zero);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc + idx + kp[0];
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 struct Result { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Result> g_results;
 
@@ -537,6 +609,9 @@ int main(int argc, char **argv) {
         for (auto &v : h) { sd = sd * 1664525u + 1013904223u; v = sd >> 3; }
         CHECK(hipMemcpy(recs, h.data(), nrec * 64, hipMemcpyHostToDevice));
         const uint32_t m = (uint32_t)nrec - 1;
+        float4 *boxes2;  // the pops' boxes of k_step32: a second array of the same size (same random contents)
+        CHECK(hipMalloc(&boxes2, nrec * 64));
+        CHECK(hipMemcpy(boxes2, h.data(), nrec * 64, hipMemcpyHostToDevice));
         for (int w : {2, 6}) {
             if (only_node ? w != 6 : log2rec != 16u) continue;
             timed(nm("load4x16B_lane_divergent"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_loadcost<0><<<n, 64>>>(recs, m, 1024, o, c); }, "64 lanes x own 64-B record");
@@ -582,11 +657,18 @@ int main(int argc, char **argv) {
                 timed(nm("step_fetch_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<1><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed(nm("step_coop_fetch_and_2_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<3><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed(nm("step_coop_fetch_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<4><<<n, 64>>>(recs, m, 1024, o, c); });
+                timed(nm("step_coop_fetch_and_2_quick_box_tests"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<3, true><<<n, 64>>>(recs, m, 1024, o, c); });
+                // round 5: the 32-byte implicit-plane record (k_step32) over the same bytes: 2 x as many records, a second array of the same size for the pops' boxes
+                timed(nm("step_fetch32B_only"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<1, 0><<<n, 64>>>(recs, recs, 2 * m + 1, 1024, o, c); });
+                timed(nm("step_fetch32B_implicit_and_2_quick_box_tests_pop0"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 0><<<n, 64>>>(recs, boxes2, 2 * m + 1, 1024, o, c); });
+                timed(nm("step_fetch32B_implicit_and_2_quick_box_tests_pop25"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 25><<<n, 64>>>(recs, boxes2, 2 * m + 1, 1024, o, c); });
+                timed(nm("step_fetch32B_implicit_and_2_quick_box_tests_pop50"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 50><<<n, 64>>>(recs, boxes2, 2 * m + 1, 1024, o, c); });
                 timed("step_2_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed("step_2_quick_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2, true><<<n, 64>>>(recs, m, 1024, o, c); });
             }
         }
         CHECK(hipFree(recs));
+        CHECK(hipFree(boxes2));
     }
     if (json) {
         printf("{");
