@@ -497,6 +497,30 @@ def main():
             ts.append((time.perf_counter() - t1) * 1e3)
         single_ms = float(np.median(ts[2:]))
 
+    # ---- the opt-in nearest-child-first walk beside it (untimed for `value`): what exactness costs. The default walks every tree in the
+    #      reference's order — the only order proven to return the reference's winner (csrc/hip/device_scene.h, tests/golden/order_adversary.npz)
+    nearest = None
+    if world == 1:
+        be.set_nearest_first(1024)
+        ts = []
+        for _ in range(max(3, len(reps))):
+            r.set_seed(5489)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_passes(r, K)
+            be.finish()
+            ts.append((time.perf_counter() - t1) / K * 1e3)
+        nf_frame = r.read_radiance(False)
+        be.set_nearest_first(0xffffffff)
+        r.set_seed(5489)
+        run_passes(r, K)
+        same = not bool((nf_frame[..., :3].view(np.uint32) != r.read_radiance(False)[..., :3].view(np.uint32)).any())
+        del nf_frame
+        nearest = {"ms_per_step": round(float(np.median(ts)), 4), "same_frame_as_default": same,
+                   "note": "gpuart_hip_set_nearest_first(1024): the round-4 default (nearer child first + certificate, ~17 % fewer node visits), opt-in "
+                           "since round 5 because the reference's phantom hits at grazing angles make any pruning walk in another order unprovable; "
+                           "the same K passes, median of %d sequences; `same_frame_as_default`: its accumulator == the default walk's, bit for bit" % max(3, len(reps))}
+
     # ---- roofline (gpuart_amd/bench_line.py): counters from rocprofv3 child runs of this invocation that render the timed shape ----
     ms_step = elapsed / K * 1e3
     prof = trace = None
@@ -538,7 +562,8 @@ def main():
         "value_definition": BL.VALUE_DEFINITION,
         "metric_version": BL.METRIC_VERSION,
         "metric_version_note": "1 (rounds 1-2): rays as the reference defines them; 2 (round 3): rays the fast mode executes; 3 (round 4): the same "
-                               "count, walked nearest-child-first (fewer box tests per ray). `value` is not comparable across versions — "
+                               "count, walked nearest-child-first (fewer box tests per ray); 4 (round 5): the same count, every walk in the reference's order "
+                               "(the nearest-first walk became opt-in: `nearest_first_opt_in`). `value` is not comparable across versions — "
                                "`ms_per_step` is, and `mrays_reference_defined_per_s` keeps version 1's definition",
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -567,6 +592,7 @@ def main():
         "ms_per_frame_note": "throughput figure: wall time of the K passes / K, with up to 64 passes in flight between two observations",
         "ms_per_frame_single": None if single_ms is None else round(single_ms, 4),
         "ms_per_frame_single_note": "one pass submitted and observed alone (frame time of the reference's interactive loop), median of 5",
+        "nearest_first_opt_in": nearest,
         "mpaths_per_s": round(W * H * K / elapsed / 1e6, 3),
         "rays_per_step": rays / K,
         "rays_executed_per_step": exe[0] / K,

@@ -28,8 +28,9 @@ STEP_PEAK_GVISITS = 244.7       # 64 lanes x 3.824e9 wave-steps/s: tools/ubench 
 
 VALUE_DEFINITION = ("rays EXECUTED by the timed fast mode (closest-hit + Sun-shadow BVH queries it really performs, device-counted in an untimed "
                     "mode-4 replay of the same passes) / wall time of the K timed passes")
-METRIC_VERSION = 3  # 1: reference-defined rays (rounds 1-2); 2: executed rays (round 3); 3: executed rays, nearest-child-first walks (round 4:
-                    # same ray count as 2, fewer node visits per ray) — `ms_per_step` is the figure that compares across versions
+METRIC_VERSION = 4  # 1: reference-defined rays (rounds 1-2); 2: executed rays (round 3); 3: executed rays, nearest-child-first walks (round 4:
+                    # same ray count as 2, fewer node visits per ray); 4 (round 5): executed rays, every walk in the reference's order again (the
+                    # nearest-first walk is opt-in: unprovable on the reference's phantom hits) — `ms_per_step` is the figure that compares across versions
 
 # One small set per rocprofv3 --pmc pass (a set that asks for more than the hardware collects at once aborts the profiler); TA_* and
 # TCP stall counters are left out: rocprofiler refuses them on gfx950 (profiles/r03/pmc_ta_tcp_sets_abort.txt).

@@ -469,6 +469,10 @@ class Backend:
         self._chk(self.L.gpuart_hip_scene_info(self.ctx, C.byref(nodes), C.byref(prims), C.byref(depth), C.byref(bytes_)))
         return dict(nodes=nodes.value, prims=prims.value, max_depth=depth.value, device_bytes=bytes_.value)
 
+    def set_nearest_first(self, min_prims):
+        """gpuart_hip_set_nearest_first: trees of at least min_prims primitives are walked nearer child first (opt-in; 0xffffffff: never)."""
+        self._chk(self.L.gpuart_hip_set_nearest_first(self.ctx, C.c_uint32(int(min_prims))))
+
     def scene_order(self):
         """0: nearer child first (certified); 1: the reference's order (small tree); 2: the reference's order, exact box tests."""
         o = C.c_int(-1)

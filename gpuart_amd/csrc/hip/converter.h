@@ -110,7 +110,7 @@ struct Converter {
         // Coordinates beyond 2^20 (the hostile classes use 1e10 ... 1e30): the intersectors' own arithmetic cancels there — a
         // vertex at -1e30 swallows the ray origin in `origin - v0` — and a hit parameter that is off by more than the band says
         // nothing about the box it came from. (ulp(2^20) = 0.06: no scene a float path tracer renders sensibly is excluded.)
-        static const int LEN[4] = {4, 8, 12, 12};
+        static const int LEN[4] = {4, 8, 12, 15};  // (a cone's derived constants 12..14 — width coefficient, cosB, dotAxC1 — included; pads excluded)
         for (int k = 0; k < LEN[type & 3]; k++)
             if (!(std::fabs(d[k]) <= 1048576.0f) && !(type == P_TRIANGLE && (k & 3) == 3)) return false;
         switch (type) {
@@ -130,6 +130,19 @@ struct Converter {
             const float tol = 1.0e-4f * (len + r1 + r2) + 1.0e-30f;
             for (int k = 0; k < 3; k++) if (!(std::fabs(d[k] + len * d[8 + k] - d[4 + k]) <= tol)) return false;
             if (!(std::fabs(r1 + wc * len - r2) <= tol)) return false;
+            // ... and so must the constants that POSITION the surface for cone_hit (device_scene.h; reference shaders/cone.glsl:30-135 with
+            // the host's src/core.cpp:191-226): a unit axis, dotAxC1 = axis . centre 1 (the F and H terms), cosB from the radii and the
+            // length (the normal only — but a record that lies about one derived constant is hand-made: no benefit of the doubt)
+            const float ax2 = d[8] * d[8] + d[9] * d[9] + d[10] * d[10];
+            if (len > 0 && !(std::fabs(ax2 - 1.0f) <= 1.0e-4f)) return false;
+            const float dot_c1 = d[8] * d[0] + d[9] * d[1] + d[10] * d[2];
+            if (!(std::fabs(d[14] - dot_c1) <= 1.0e-4f * (std::fabs(d[0]) + std::fabs(d[1]) + std::fabs(d[2]) + 1.0f))) return false;
+            float cosb = 0.0f;
+            if (std::fabs(r1 - r2) >= 1.0e-7f && len > 0) {
+                const float rr = r1 > r2 ? r1 : r2, h = rr * len / std::fabs(r1 - r2);
+                cosb = (r1 > r2 ? rr : -rr) / std::sqrt(h * h + rr * rr);
+            }
+            if (!(std::fabs(d[13] - cosb) <= 1.0e-3f)) return false;
             break;
         }
         default: return false;

@@ -42,39 +42,52 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #define GD_REF_SMALL 0x10000000u ///< with GD_REF_LEAF, without GD_REF_TRIS: one or two primitives of any type (GD_REF_TWO: two) — fetched at once like a triangle pair
 #define GD_REF_INDEX 0x0fffffffu
 
-// Nearest-child-first closest-hit queries (round 4). The reference always descends lower-then-upper
-// (shaders/bvh_intersection.glsl:432-441), prunes a node whose box is entered beyond the closest hit so far (:398) and keeps the
-// strictly closer hit (:416): among the hits with the smallest parameter the FIRST primitive in its depth-first order = the one
-// with the lowest address wins. If every box were conservative for what it holds — entered no later than any hit inside it — that
-// winner would not depend on the visiting order, and a walk that enters the nearer child first, stacks the other one and lets the
-// lower primitive index win equal parameters would return it after ~18 % fewer node visits. In fp32 boxes are NOT always
-// conservative: a box entry parameter and a primitive's own hit parameter are computed two ways, and where the hit lies on the
-// box's face (flat axis-aligned triangles, a sphere's axis-extreme points, a triangle's extreme vertex) either may come out a few
-// ulps larger. Then the reference's pruning — and so its winner among surfaces that (nearly) coincide — hinges on its order:
-// measured, 3 of 1e9 rays of cfg3 and every tenth scene of coplanar lattice geometry (profiles/r04/nearest_child_first.txt).
-// The fast kernels therefore walk nearest-first WITH a certificate (NEAREST template arguments below):
+// Visiting order of a closest-hit query. The reference always descends lower-then-upper (shaders/bvh_intersection.glsl:432-441),
+// prunes a node whose box is entered beyond the closest hit so far (:398) and keeps the strictly closer hit (:416): among the hits with
+// the smallest parameter the FIRST primitive in its depth-first order = the one with the lowest address wins.
+//
+// DEFAULT (round 5): every walk of the product keeps that order to the letter (the !NEAREST code below; the GD_REF_ORDER kernel variants).
+// It is the only order PROVEN to return the reference's winner, and here is why no other one can be: the reference accepts whatever
+// parameter its intersectors compute. Moeller-Trumbore at a grazing angle below ~1e-5 rad (shaders/triangle.glsl:50-76) divides two sums
+// that have cancelled to a few ulps: the quotient is a small dyadic number — 0.8, 0.25, 0.03125 — unrelated to where the triangle is,
+// and u and v, as arbitrary, sometimes pass. Such a PHANTOM hit can lie far in front of the triangle's own leaf box. The reference
+// returns it iff its walk reaches that leaf while it holds nothing closer than the box's entry — a property of ITS order. Any walk that
+// visits another child first and prunes with what it found there can skip that leaf, never test the triangle, and so cannot know: no
+// certificate computed from the primitives a walk DID test covers a primitive it did not. tests/golden/order_adversary.npz holds 16
+// such scenes (four primitives each: the phantom's triangle, a disc between phantom and box, two fillers), found in 2.5 s of search,
+// expected values from the reference's own GLSL on llvmpipe; the reference-order walk returns them bit for bit, the walk below does not.
+//
+// OPT-IN (gpuart_hip_set_nearest_first / GPUART_HIP_NEAREST_MIN_PRIMS; the default of round 4): nearest-child-first WITH a certificate
+// (NEAREST template arguments below) — ~17 % fewer node visits per query, 10 % less time per 1080p pass of cfg3 (0.74 against 0.82 ms),
+// 17 % less for one pass alone. If every box were conservative for what it holds — entered no later than any hit inside it — the
+// winner would not depend on the visiting order, and a walk that enters the nearer child first, stacks the other one and lets the lower
+// primitive index win equal parameters would return it. In fp32 boxes are NOT always conservative, in three ways of growing size:
+//   (1) rounding: a box entry parameter and a primitive's own hit parameter are computed two ways, and where the hit lies on the box's
+//       face (flat axis-aligned triangles, a sphere's axis-extreme points, a triangle's extreme vertex) either may come out a few ulps
+//       larger: 3 of 1e9 rays of cfg3, every tenth scene of coplanar lattice geometry (profiles/r04/nearest_child_first.txt);
+//   (2) "odd" boxes: the face the ray enters through fails its own test by rounding at an edge, the reference's running minimum falls
+//       on the face the ray leaves through, and the box claims to be entered beyond hits inside it by up to its whole depth (1 ray in ~1e8);
+//   (3) phantom hits (above): off by any factor. NOT covered by what follows.
+// The certificate covers (1) and (2):
 //   * pruning is widened by GD_NEAREST_BAND: a node is skipped only if its entry parameter exceeds closest x BAND, so every
 //     primitive within the band of the final hit is tested whatever the order;
 //   * the query tracks the runner-up (second smallest accepted parameter) and whether the winner is "loose": some box on its
 //     path is entered beyond the winner's own parameter (only then can the reference have pruned it) — its leaf's box, in fact:
-//     without odd boxes (next item) entry parameters never decrease towards the leaves (aabb_entry);
-//   * a box is "odd" when its reported entry parameter is not its slab entry (aabb_entry): the face the ray enters through failed
-//     its own test by rounding at an edge, the reference's running minimum fell on the face the ray leaves through, and the box
-//     claims to be entered beyond hits that lie inside it — by up to its whole depth; what the reference finds there depends on
-//     when its walk arrives;
+//     without odd boxes entry parameters never decrease towards the leaves (aabb_entry);
+//   * a box whose reported entry parameter is not its slab entry (aabb_entry's `odd`) marks the query;
 //   * a finished query that met an odd box, or whose winner is adrift of its boxes by more than the band, or whose winner is loose
-//     AND has a runner-up within the band, is walked again in the reference's order (about ten queries per million: 55 of 4.7e6 per 1080p pass of cfg3) — trav_settle;
+//     AND has a runner-up within the band, is walked again in the reference's order (about ten queries per million: 55 of 4.7e6 per
+//     1080p pass of cfg3) — trav_settle;
 //   * trees whose boxes do not bound their contents at all (hostile input: converter.h prim_in_box) never walk nearest-first.
-// Why this suffices: let (t*, p*) be the nearest-first result, R the reference's. If every hit primitive's boxes are entered no
-// later than its parameter x (1 + eps), with BAND >= (1 + eps)^2: R was tested by the nearest-first walk, so t_R >= t*; the
-// reference can only have missed p* through a box on p*'s path entered beyond t* (p* loose) while it held another hit with
-// t* <= t < that entry (a runner-up within the band) — and when it did test p*, the winner by (parameter, index) is the same in
-// both walks. eps is 0.2 % (BAND = 1 + 2^-8) = 32 000 ulps here; a primitive whose computed parameter is off by more (a triangle
-// hit at a grazing angle below ~1e-4 rad) AND that this walk prunes while the reference, arriving with nothing closer, accepts it
-// is outside the certificate; a winner that is off by that much is caught (adrift), and so is any box whose reported entry parameter
-// is not its slab entry (aabb_entry's `odd`: the other source of gross non-conservativeness). Measured: tools/order_soak.py, 2e11
-// rays of six scenes against the reference-order kernels without a differing pixel. The counting "reference work" variants, trees
-// with irregular boxes and the one-thread-per-pixel kernels keep the reference's order throughout.
+// What that proves: let (t*, p*) be the nearest-first result, R the reference's. IF every primitive the reference accepts has a computed
+// parameter no smaller than the entry parameter of each of its boxes / (1 + eps), with (1 + eps)^2 <= BAND — eps <= 0.195 % for
+// BAND = 1 + 2^-8 —, then R was tested by the nearest-first walk, so t_R >= t*; the reference can only have missed p* through a box on
+// p*'s path entered beyond t* (p* loose) while it held another hit with t* <= t < that entry (a runner-up within the band) — and when
+// it did test p*, the winner by (parameter, index) is the same in both walks. The IF is (3)'s complement; it fails for a triangle
+// grazed below ~1e-4 rad (relative error of the computed parameter ~ 8 u / |cos(ray, normal)|), a disc likewise, and no walk can check
+// it for primitives it does not test. Measured: tools/order_soak.py, 3.7e11 rays of six scenes against the reference-order kernels
+// without a differing pixel (profiles/r04/order_soak_final.txt) — soak-verified, not proven; hence opt-in. The counting "reference work"
+// variants, trees with irregular boxes, Sun-shadow queries and the one-thread-per-pixel kernels keep the reference's order in any case.
 #ifndef GD_NEAREST
 #define GD_NEAREST 1
 #endif
@@ -246,9 +259,8 @@ GD_FN float triangle_t(float rox, float roy, float roz, float rdx, float rdy, fl
 /// types is not generated, which is worth 15 VGPRs — a fifth wave per SIMD — in the BVH-query kernel).
 #define GD_ALL_TYPES 0xF
 #define GD_EXACT_BOXES 0x10  ///< beside a type mask: the kernel variant for trees with irregular boxes (box tests in comparison form)
-#define GD_REF_ORDER 0x20    ///< beside a type mask: regular boxes, but every walk keeps the reference's order — small trees, where the
-                             ///< certificate's bookkeeping costs more than the nearer-child-first order saves (Scene P, 273 primitives:
-                             ///< 0.432 against 0.447 ms per pass; profiles/r04/small_trees_keep_the_reference_order.txt)
+#define GD_REF_ORDER 0x20    ///< beside a type mask: regular boxes, every walk keeps the reference's order — the product's default since round 5
+                             ///< (top of this file); without it: the opt-in nearest-child-first variants
 #define GD_NEAREST_OF(TYPES) (GD_NEAREST && !((TYPES) & (GD_EXACT_BOXES | GD_REF_ORDER)))
 /// How a kernel tests boxes: the fast (med3) form, the exact comparison form, or whichever Scene::exact_boxes asks for
 /// (kernels off the fast path: one wave-uniform branch per step).

@@ -125,7 +125,9 @@ struct gpuart_hip_ctx {
     int pend_npaths = 0;
     uint64_t n_nodes = 0, n_prims = 0, scene_bytes = 0;
     uint32_t ref_order = 0;       ///< a small tree of regular boxes: the fast kernels keep the reference's order (GD_REF_ORDER variants)
-    uint32_t nearest_min_prims = 1024;  ///< GPUART_HIP_NEAREST_MIN_PRIMS: trees with fewer primitives keep the reference's order
+    uint32_t nearest_min_prims = 0xffffffffu;  ///< GPUART_HIP_NEAREST_MIN_PRIMS / gpuart_hip_set_nearest_first: trees with at least this many primitives are
+                                                ///< walked nearer child first (OPT-IN since round 5: that walk is not the reference's on phantom hits,
+                                                ///< device_scene.h); default: never — every walk keeps the reference's order
     uint32_t type_mask = 0;  ///< bit t set: the scene holds primitives of type t
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = 0;
@@ -436,7 +438,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->tune.leaf_share = env_u32("GPUART_HIP_LEAF_SHARE", 3, 1, 64);
     c->tune.xcd_queues = env_u32("GPUART_HIP_XCD_QUEUES", 0, 0, 1);
     c->order_auto = env_u32("GPUART_HIP_TILE_ORDER", 1, 0, 1) != 0;
-    c->nearest_min_prims = env_u32("GPUART_HIP_NEAREST_MIN_PRIMS", 1024, 0, 0x7fffffff);
+    c->nearest_min_prims = getenv("GPUART_HIP_NEAREST_MIN_PRIMS") ? env_u32("GPUART_HIP_NEAREST_MIN_PRIMS", 1024, 0, 0x7fffffff) : 0xffffffffu;
     c->quick_boxes = env_u32("GPUART_HIP_QUICK_BOXES", 1, 0, 1);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(GPUART_HIP_ERR_DEVICE, "hipStreamCreate failed"); }
     c->lanes.resize(env_u32("GPUART_HIP_PASSES_IN_FLIGHT", 8, 1, 32));
@@ -727,7 +729,11 @@ int launch_run_persistent(gpuart_hip_ctx *c, PassLane &l, size_t first, size_t c
     const bool round_only = c->lean_kernels && !c->exact_boxes && !flat_only && (c->type_mask & ~(uint32_t)GD_ROUND_TYPES) == 0;  // spheres + discs
     const bool exact = c->exact_boxes != 0;  // a tree with irregular boxes: the kernel variants with comparison-form box tests
     // k_run's list entries carry the path slot in RUN_SLOT's bits beside their flags
-    if ((uint64_t)b.n_slots * b.batch > (uint64_t)RUN_SLOT) return fail(GPUART_HIP_ERR_DEVICE, "internal: a run of more path slots than k_run's list entries address");
+    // (the LARGEST slot index, n_slots x batch - 1, must fit: a run of exactly 2^28 slots does; the planner never plans a longer one
+    //  for mode 0 — run_planner.h RUN_KERNEL_SLOTS — so only modes 1 / 4 / 5 on a tile beyond 2^28 pixels can get here)
+    if ((uint64_t)b.n_slots * b.batch > (uint64_t)RUN_SLOT + 1)
+        return fail(GPUART_HIP_ERR_ARG, "modes 1, 4 and 5 run through k_run, whose list entries address 2^28 path slots per run; this tile has " +
+                    std::to_string((uint64_t)b.n_slots * b.batch) + " (use mode 0 or 3, or a smaller tile)");
     const uint32_t chunks = b.n_slots * b.batch / BLOCK;
     const dim3 grid(std::min<uint32_t>(c->run_waves, std::max<uint32_t>(1, chunks)));
     TimedLaunch t;
@@ -975,6 +981,15 @@ int gpuart_hip_counters(gpuart_hip_ctx *c, gpuart_counters *out, int reset) {
         out->rewalks = h[9];
     }
     if (reset) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof h, c->stream));
+    return 0;
+}
+
+int gpuart_hip_set_nearest_first(gpuart_hip_ctx *c, uint32_t min_prims) {
+    if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    { int fr = gpuart_hip_flush(c); if (fr) return fr; }  // (passes collected so far were requested under the old choice; both give... the reference's image or, opted in, the walk's)
+    c->nearest_min_prims = min_prims;
+    if (c->have_scene) c->ref_order = (!c->exact_boxes && c->n_prims < c->nearest_min_prims) ? 1u : 0u;
     return 0;
 }
 

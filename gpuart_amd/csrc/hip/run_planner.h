@@ -35,6 +35,7 @@ struct RunPlanner {
     size_t pending = 0;           ///< passes collected, not launched yet
 
     static constexpr size_t PATH_BYTES = 6 * 16 + 8 + 3 * 4;  ///< path state per slot: six float4, one uint2, three queue words
+    static constexpr size_t RUN_KERNEL_SLOTS = (size_t)1 << 28; ///< k_run's list entries address this many path slots of one run (kernel_run.h RUN_SLOT)
 
     /// Bytes of one lane's path state for runs of `batch` passes.
     size_t lane_bytes(size_t batch) const { return (size_t)n_slots * batch * PATH_BYTES + batch * tile_pixels * 16; }
@@ -44,7 +45,7 @@ struct RunPlanner {
     void set_tile(uint32_t slots, size_t pixels) {
         n_slots = slots; tile_pixels = pixels; pending = 0;
         if (!n_slots) { max_batch = 1; lanes_in_use = 1; run_passes = 1; return; }
-        max_batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(batch_limit, batch_paths / n_slots));
+        max_batch = (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)batch_limit, batch_paths / n_slots, RUN_KERNEL_SLOTS / n_slots}));
         first_lanes();
         plan();
     }
@@ -66,6 +67,7 @@ struct RunPlanner {
     bool uses_run_kernel(size_t count) const {
         if (mode == 1 || mode == 4 || mode == 5) return true;
         if (mode != 0 || !small_paths) return false;
+        if ((size_t)n_slots * count > RUN_KERNEL_SLOTS) return false;  // (a tile beyond 2^28 pixels: one pass alone goes through the launch pipeline)
         const size_t passes = planned_passes ? planned_passes : count;
         return passes <= 1 || passes * (size_t)n_slots <= small_paths;  // one pass observed alone: k_run at every frame size
     }

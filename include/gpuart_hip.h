@@ -242,10 +242,17 @@ int gpuart_hip_kernel_time(gpuart_hip_ctx *ctx, int cls, double *total_ms, uint6
 int gpuart_hip_scene_info(gpuart_hip_ctx *ctx, uint64_t *nodes, uint64_t *prims, uint32_t *max_depth,
                           uint64_t *device_bytes);
 
-/* How the fast kernels walk the uploaded tree: 0 nearer child first with a certificate; 1 in the reference's
- * order because the tree is small (fewer than GPUART_HIP_NEAREST_MIN_PRIMS primitives, default 1024: the certificate's bookkeeping
- * costs more than the order saves there); 2 in the reference's order with comparison-form box tests, because a box is irregular or does
- * not bound its contents (gpuart_hip_test_tree_class). Images are the same bits in all three. */
+/* How the fast kernels walk the uploaded tree: 1 (the default for every tree of regular boxes since round 5) in the reference's order —
+ * lower child first, shaders/bvh_intersection.glsl:432-441 — which is the only order PROVEN to return the reference's winner; 2 in the
+ * reference's order with comparison-form box tests, because a box is irregular or does not bound its contents
+ * (gpuart_hip_test_tree_class); 0 nearer child first with a certificate and a second walk where the certificate fails — ~10 % fewer node
+ * visits, OPT-IN: gpuart_hip_set_nearest_first(ctx, min_prims) or GPUART_HIP_NEAREST_MIN_PRIMS=min_prims in the environment at
+ * gpuart_hip_create (trees of at least min_prims primitives; 0xffffffff: never). Why opt-in: the reference accepts whatever parameter
+ * its intersectors compute, and at grazing angles below ~1e-5 rad triangle.glsl:50-76 computes phantom hits far in front of the
+ * triangle's own box; a walk that prunes that box after seeing a surface in between never tests the triangle and returns another winner
+ * than the reference (tests/golden/order_adversary.npz: 16 constructed scenes, expected values from the reference's GLSL). No image of
+ * a 3.7e11-ray soak of the benchmark scenes ever differed — the walk is soak-verified, not proven. */
+int gpuart_hip_set_nearest_first(gpuart_hip_ctx *ctx, uint32_t min_prims);
 int gpuart_hip_scene_order(gpuart_hip_ctx *ctx, int *order);
 
 /* ---- run planner test hook (pure host code: needs no device and no context) ------------------

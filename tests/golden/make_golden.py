@@ -784,8 +784,138 @@ def gen_dragon871k(gl):
     save("frames_dragon871k_seg8", scene="dragon871k", W=128, H=72, cam=r.cam, max_segments=8, npasses=2, seeds=seeds, bvh_depth=depth, **out)
 
 
+# ---- the adversary of the nearest-child-first walk (round 5) ----------------------------------------------------------------
+# A walk that visits a node's children in another order than the reference's (lower child first, shaders/bvh_intersection.glsl:432-441)
+# and prunes on the closest hit so far returns the reference's winner only if every primitive the reference TESTS and this walk does
+# not has a parameter beyond the winner's. The reference accepts whatever parameter its intersector computes — and Moeller-Trumbore
+# (shaders/triangle.glsl:50-76) at a grazing angle below ~1e-5 rad computes det and the numerator from sums that cancel to a few
+# ulps: t = (a few ulps) / (a few ulps), any small dyadic number, while u and v (as arbitrary) happen to pass. Such a hit can lie far
+# IN FRONT of its own leaf box. Put a surface S between that phantom hit and the box: the reference, arriving at the triangle's
+# leaf first with nothing closer, tests it and keeps the phantom; a walk that sees S first prunes the leaf (entered beyond S by more
+# than any band) and never tests the triangle — no certificate computed from what the walk DID test can notice.
+def _nf_parse(tree):
+    q = tree.view(np.uint32).reshape(-1, 4); f = tree.reshape(-1, 4)
+    nodes = {}
+
+    def rd(a):
+        flags = int(q[a + 2, 0])
+        n = {"min": f[a, :3].copy(), "max": f[a + 1, :3].copy(), "leaf": bool(flags >> 31 & 1)}
+        if n["leaf"]:
+            prims, p = [], a + 3
+            for _ in range(flags & 0x1fffffff):
+                t = int(q[p, 0]); nd = t + 1
+                prims.append((p, t, f[p + 1:p + 1 + nd].copy())); p += 1 + nd
+            n["prims"] = prims
+        else:
+            n["lo"], n["hi"] = int(q[a + 2, 1]), int(q[a + 2, 2]); rd(n["lo"]); rd(n["hi"])
+        nodes[a] = n
+    rd(0)
+    return nodes
+
+
+def _nf_walk(nodes, o, d, band=np.float32(1.00390625)):
+    """Model of the device's nearest-child-first closest-hit walk WITH its certificate (gpuart_amd/csrc/hip/device_scene.h: trav_step_box,
+    take_hit, trav_settle), on the oracle's box test and intersectors: (closest, winner's address, whether the certificate asks for a second walk)."""
+    f32 = np.float32
+    v4 = lambda v: np.append(v, 0)[None].astype(f32)
+
+    def box(n):
+        a = O.aabb(v4(o), v4(d), v4(n["min"]), v4(n["max"]))[0]
+        rdiv = (f32(1) / d).astype(f32)
+        k0, k1 = ((n["min"] - o).astype(f32) * rdiv).astype(f32), ((n["max"] - o).astype(f32) * rdiv).astype(f32)
+        slab = np.max(np.minimum(k0, k1))
+        hit = a[0] > 0
+        return hit, a[1], bool(hit and a[1] != -1 and a[1] != min(slab, f32(1e19)))
+
+    def prim(pr):
+        _, t, data = pr
+        if t == 2: r = O.triangle(v4(o), v4(d), data[0][None], data[1][None], data[2][None])[0][0, 0]
+        elif t == 1: r = O.disc(v4(o), v4(d), data[0][None], data[1][None])[0][0, 0]
+        else: r = O.sphere(v4(o), v4(d), data[0][None])[0][0, 0]
+        return r if r >= f32(1e-4) else f32(-1)
+    closest = second = f32(1e19); win, flags, odd = None, 0, False
+    h, e, od = box(nodes[0])
+    if not h:
+        return closest, None, False
+    odd |= od
+    stack, cur = [], (0, e)
+    while True:
+        a, entry = cur; n = nodes[a]; nxt = None
+        if n["leaf"]:
+            for pr in n["prims"]:
+                t = prim(pr)
+                if t > 0:
+                    w = t < closest or (t == closest and (win is None or pr[0] < win))
+                    second = min(second, closest if w else t)
+                    if w:
+                        closest, win, flags = t, pr[0], (1 if entry > t else 0) | (2 if entry > t * band else 0)
+        else:
+            hl, el, ol = box(nodes[n["lo"]]); hh, eh, oh = box(nodes[n["hi"]]); odd |= ol | oh
+            en, ef, rn, rf = (el if hl else f32(3e38)), (eh if hh else f32(3e38)), n["lo"], n["hi"]
+            if ef < en: en, ef, rn, rf = ef, en, rf, rn
+            if not ef > closest * band: stack.append((rf, entry, ef))
+            if not en > closest * band: nxt = (rn, en)
+        while nxt is None:
+            if not stack:
+                return closest, win, bool(odd or (win is not None and ((flags & 2) or ((flags & 1) and second <= closest * band))))
+            rf, pe, he = stack.pop()
+            if pe > closest * band or he > closest * band: continue
+            nxt = (rf, he)
+        cur = nxt
+
+
+def gen_order_adversary(gl):
+    """tests/golden/order_adversary.npz: scenes of four primitives + one ray each on which the reference (its own GLSL, here) returns a
+    triangle's PHANTOM hit — a parameter far in front of the triangle's own box, from cancelled sums at a grazing angle — while a
+    nearest-child-first walk, certificate included, returns the surface that stands between (model above; the device's walk is held
+    to it in tests/test_gpu_parity.py). Search: seeded; the oracle's intersector finds candidate rays, the reference's GLSL has the say."""
+    f32 = np.float32
+    rng = np.random.RandomState(20261005)
+
+    def rot():
+        q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    body = ("float pos; vec3 p, n; int t; bool ush; CheckIntersectionInclUserSphere(i0.xyz, i1.xyz, BVH, i2, pos, p, n, t, ush);"
+            "if (t >= 0) { O0 = vec4(pos, p); O1 = vec4(n, float(t) + (ush ? 0.5 : 0.0)); } else { O0 = vec4(-1, 0, 0, 0); O1 = vec4(0, 0, 0, -1); }")
+    objs = ["sphere.glsl", "disc.glsl", "triangle.glsl", "cone.glsl", "common.glsl", "noise.glsl", "bvh_intersection.glsl", "intersection.glsl"]
+    cases = {}
+    while len(cases) < 16 * 6:
+        eps, s, R, c = 10 ** rng.uniform(-6.5, -5), 10 ** rng.uniform(-1.5, -0.5), rot(), rng.uniform(-1, 1, 3)
+        V = (np.array([[0, 0, 0], [s, 0.1 * s, 0], [0.3 * s, 0.9 * s, 0]]) @ R.T + c).astype(f32)   # a well-shaped triangle, any orientation
+        n = 100000
+        ol = np.zeros((n, 3)); ol[:, 0] = -2.0 + rng.uniform(-0.5, 0.5, n); ol[:, 1] = rng.uniform(0, s, n); ol[:, 2] = rng.uniform(-4, 4, n) * eps
+        tgt = np.zeros((n, 3)); tgt[:, 0] = rng.uniform(0, s, n); tgt[:, 1] = rng.uniform(0, s, n)
+        dl = tgt - ol; dl[:, 2] += rng.uniform(-1, 1, n) * eps * 0.5                                     # rays that graze its plane by ~eps rad
+        o, d = pad4((ol @ R.T + c).astype(f32)), pad4((dl @ R.T).astype(f32))
+        t = O.triangle(o, d, *[np.tile(pad4(V[k][None]), (n, 1)) for k in range(3)])[0][:, 0]
+        a = O.aabb(o, d, np.tile(pad4(V.min(0)[None]), (n, 1)), np.tile(pad4(V.max(0)[None]), (n, 1)))
+        bad = np.flatnonzero((t > 0) & (a[:, 0] > 0) & (a[:, 1] > 0) & (t * 1.05 < a[:, 1]))            # the hit lies 5 % and more in front of the triangle's box
+        if not len(bad):
+            continue
+        k = bad[np.argmax(a[bad, 1] / t[bad])]
+        ray_o, ray_d, tp, eT = o[k, :3], d[k, :3], t[k], a[k, 1]
+        for _ in range(40):
+            tS = f32(rng.uniform(tp * 1.002, eT / 1.01))                                                   # S: a disc across the ray between phantom and box
+            cS = ray_o.astype(np.float64) + tS * ray_d.astype(np.float64)
+            tri = lambda cc, sz: (2, list((cc + rng.normal(size=3) * sz)) + list((cc + rng.normal(size=3) * sz)) + list((cc + rng.normal(size=3) * sz)))
+            prims = [(2, list(V.reshape(-1).astype(float))), tri(V.mean(0) + rng.normal(size=3) * 0.3, 0.01),
+                     (1, list(cS) + list(ray_d / np.linalg.norm(ray_d)) + [float(rng.uniform(0.005, 0.05))]), tri(cS + rng.normal(size=3) * 0.3, 0.01)]
+            tree, _ = O.build_bvh(prims)
+            r0, r1 = O.traverse(tree, pad4(ray_o[None]), pad4(ray_d[None]), (0, 0, 0, 0))
+            cl, win, again = _nf_walk(_nf_parse(tree), ray_o, ray_d)
+            if r1[0, 3] >= 0 and win is not None and r0[0, 0] != cl and not again:
+                g0, g1 = glref.run_probe_big(gl, body, objs, [pad4(ray_o[None]), pad4(ray_d[None]), np.zeros((1, 4), f32)], 2, bvh=tree, decls=D_INCL, chunk=4096)
+                if g0[0, 0] != cl:   # the reference's GLSL agrees that the walk's answer is not the reference's
+                    i = len(cases) // 6
+                    cases.update({"tree%d" % i: tree, "rs%d" % i: ray_o, "rd%d" % i: ray_d, "o0_%d" % i: g0[0], "o1_%d" % i: g1[0], "nf%d" % i: f32(cl)})
+                    print("order_adversary %2d: reference t = %.6f (type %g), nearest-first walk t = %.6f; the triangle's box is entered at %.6f" % (i, g0[0, 0], g1[0, 3], cl, eT))
+                break
+    save("order_adversary", n=len(cases) // 6, **cases)
+
+
 SECTIONS = dict(dragon871k=gen_dragon871k, lattice=gen_lattice, scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, order_rays=gen_order_rays, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, order_rays=gen_order_rays, order_adversary=gen_order_adversary, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

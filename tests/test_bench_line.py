@@ -172,7 +172,7 @@ def test_bench_py_uses_the_shared_definitions():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "BL.assemble_roofline(" in src and "BL.VALUE_DEFINITION" in src and "BL.METRIC_VERSION" in src
     assert "--render-only" in src and "PROFILE_REPEATS" in src
-    assert BL.METRIC_VERSION == 3
+    assert BL.METRIC_VERSION == 4
 
 
 def _lines():
@@ -214,7 +214,7 @@ def test_committed_bench_lines_keep_the_contract(rnd, name):
         for name in BL.RATIO_QUANTITIES:
             assert (r if name == "" else r[name])["quantity"] == BL.RATIO_QUANTITIES[name]
     if rnd >= "r04":  # round 4's additions
-        assert d["metric_version"] == 3 and "value_definition" in d
+        assert d["metric_version"] == (3 if rnd == "r04" else 4) and "value_definition" in d
         if rnd == "r04":
             assert r["bound"] == "valu_lanes" and abs(r["frac"] - r["valu_issue"]["frac"] * r["valu_issue"]["lane_util"]) < 2e-3
         ws = r["k_trace_wave_states"]

@@ -384,5 +384,16 @@ def test_uploader_classifies_trees_for_the_visiting_order():
     k = int([r for r in rows if ctree[r, 1] == 0 and ctree[r, 2] == 0][0])  # the cone's type quad; its data quads follow
     bent = ctree.copy(); bent[k + 3, 0:3] = (1.0, 0.0, 0.0)                # axis no longer points from centre 1 to centre 2
     assert B.tree_class(bent)["disorderly"]
+    # ... or whose derived constants lie about it: dotAxC1 positions the surface cone_hit intersects, cosB its normal, the axis must be a unit vector
+    # (the data quads: {c1, r1}{c2, r2}{axis, len}{widthCoeff, cosB, dotAxC1, pad}, reference src/core.cpp:230-245)
+    for col, delta in ((2, 0.05), (1, 0.05), (0, 0.05)):
+        lied = ctree.copy(); lied[k + 4, col] += delta
+        assert B.tree_class(lied)["disorderly"], "cone constant %d off by %g went unnoticed" % (col, delta)
+    scaled = ctree.copy(); scaled[k + 3, 0:3] *= 1.5; scaled[k + 3, 3] /= 1.5   # axis x 1.5, length / 1.5: centre 2 still agrees, the axis is no unit vector
+    assert B.tree_class(scaled)["disorderly"]
+    for seed in range(40):   # the honest cones of the random classes stay order-free (the check compares with the reference's own double-precision formulas)
+        case = S.random_case(seed)["prims"]
+        if any(t == S.CONE for t, _ in case):
+            assert not T(case)["disorderly"], seed
     with pytest.raises(B.HipError, match="malformed"):
         B.tree_class(tree[:5])

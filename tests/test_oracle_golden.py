@@ -223,6 +223,22 @@ def test_rays_through_boxes_that_report_their_exit_as_their_entry():
         assert_bits(np.concatenate([o0, o1], 1), np.concatenate([g[name + "_o0"], g[name + "_o1"]], 1), "order rays " + name)
 
 
+def test_phantom_hits_of_grazing_triangles():
+    """tests/golden/order_adversary.npz (make_golden.py order_adversary): 16 rays that graze a triangle by ~1e-6 rad; the reference's
+    GLSL returns a phantom hit of that triangle — a small dyadic parameter from two cancelled sums (shaders/triangle.glsl:50-76), far in
+    front of the triangle's own box and in front of the disc that stands before it. The oracle's walk (the reference's order, the
+    reference's arithmetic) must return the same bits; its intersector alone must show the same phantom. This fixture is why the
+    product walks every tree in the reference's order (tests/test_gpu_parity.py::test_phantom_hits_are_why_nearest_first_is_opt_in)."""
+    g = golden("order_adversary")
+    n = int(g["n"])
+    assert n >= 16
+    for i in range(n):
+        rs, rd = pad4(g["rs%d" % i][None]), pad4(g["rd%d" % i][None])
+        o0, o1 = O.traverse(g["tree%d" % i], rs, rd, (0, 0, 0, 0))
+        assert_bits(np.concatenate([o0, o1], 1), np.concatenate([g["o0_%d" % i], g["o1_%d" % i]])[None], "adversary %d" % i)
+        assert o1[0, 3] == 2.0 and o0[0, 0] < g["nf%d" % i]  # the triangle wins, in front of what a nearest-first walk finds
+
+
 FRAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "frames_*.npz")))
 
 

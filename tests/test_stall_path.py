@@ -195,6 +195,8 @@ def test_the_read_back_wait_of_gather_all_read_is_bounded(stub):
     when the stream frees itself the same call works, and comm_destroy of the context that gave up is bounded too."""
     _held("none", stub, """
 B.comm_init_all([be])
+full = B.gather_all_read([be], 1, 2.0, 0, W, H)     # (first use allocates the send / staging buffers: hipMalloc and hipFree may wait for the device)
+assert (full.view(np.uint32) == own.view(np.uint32)).all()
 be.test_stall(1500)
 t0 = time.perf_counter()
 try:
