@@ -283,14 +283,8 @@ def gather_all_read(backends, which, divide_by, root, W, H):
     L = hip_lib()
     arr = (C.c_void_p * len(backends))(*[b.ctx for b in backends])
     out = np.empty((H, W, 4), np.float32)
-    rc = L.gpuart_hip_gather_all_read(arr, len(backends), which, C.c_float(divide_by), root, _p(out))
-    if rc == ERR_TIMEOUT:
-        _abandoned.append(out)  # the read-back is still queued behind the rows that never came: its target must outlive the call
-    backends[0]._chk(rc)
+    backends[0]._chk(L.gpuart_hip_gather_all_read(arr, len(backends), which, C.c_float(divide_by), root, _p(out)))
     return out
-
-
-_abandoned = []
 
 
 class HipError(RuntimeError):

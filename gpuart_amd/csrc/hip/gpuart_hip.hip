@@ -156,6 +156,8 @@ struct gpuart_hip_ctx {
     float4 *d_send = nullptr, *d_stage = nullptr;
     size_t send_pixels = 0, stage_pixels = 0;
     void *d_hello = nullptr;          ///< [1 + nranks] GatherHello: own share + status, then everybody's (ncclAllGather)
+    void *h_frame = nullptr;          ///< pinned landing area of gpuart_hip_gather_all_read's read-back (the bounded wait comes after the copy is queued)
+    size_t h_frame_bytes = 0;
     void *h_hello = nullptr;          ///< pinned host copy of that table: the exchange's device-to-host copy must be truly asynchronous
                                       ///< (the bounded wait comes AFTER it is queued) and its target must outlive a timed-out call
     uint64_t comm_group = 0;          ///< which communicator this context is a rank of: contexts joined by one _comm_init_all (or one
@@ -499,6 +501,7 @@ int gpuart_hip_destroy(gpuart_hip_ctx *c) {
     for (void *p : comm_ptrs) if (p && !comm_stuck) (void)hipFree(p);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->h_hello && !comm_stuck) (void)hipHostFree(c->h_hello);  // (after drain: no copy into it is queued any more)
+    if (c->h_frame && !comm_stuck) (void)hipHostFree(c->h_frame);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1447,10 +1450,19 @@ int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, fl
     HIP_TRY(hipSetDevice(c->device));
     // The copy is queued behind the root's receives: waiting for it is waiting for every peer's rows. Bounded like the exchange of
     // gpuart_hip_gather (this wait was a plain hipStreamSynchronize until round 5 — one of the three unbounded waits on the path
-    // of the gpuart_cli child that once did not end, profiles/r05/stall_path.txt). A caller whose wait runs out must keep
-    // full_frame_host alive until the process ends (the queued copy may still land in it): gpuart_cli and bench.py exit.
-    HIP_TRY(hipMemcpyAsync(full_frame_host, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
-    return wait_stream(c, c->gather_timeout_ms, "gather: the peers' rows and the read-back of the frame");
+    // of the gpuart_cli child that once did not end, profiles/r05/stall_path.txt). The device-to-host copy goes into PINNED memory
+    // owned by the context: into the caller's pageable buffer hipMemcpyAsync is not asynchronous — the call itself would wait for
+    // the stream, ahead of the bounded wait (the first version of this fix did exactly that; the test that holds the stream caught
+    // it) — and a call that gives up leaves no queued copy pointing at memory the caller may free.
+    if (c->h_frame_bytes < bytes) {
+        if (c->h_frame) { (void)hipHostFree(c->h_frame); c->h_frame = nullptr; c->h_frame_bytes = 0; }
+        if (hipHostMalloc(&c->h_frame, bytes, hipHostMallocDefault) != hipSuccess) { c->h_frame = nullptr; return fail(GPUART_HIP_ERR_DEVICE, "gather: no pinned host memory for the frame"); }
+        c->h_frame_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_frame, c->d_scratch, bytes, hipMemcpyDeviceToHost, c->stream));
+    if ((r = wait_stream(c, c->gather_timeout_ms, "gather: the peers' rows and the read-back of the frame"))) return r;
+    memcpy(full_frame_host, c->h_frame, bytes);
+    return 0;
 }
 
 // ---- uploader hook: what gpuart_hip_upload_bvh decides about a tree, without a device (include/gpuart_hip.h) ----------
