@@ -517,7 +517,7 @@ def main():
         same = not bool((nf_frame[..., :3].view(np.uint32) != r.read_radiance(False)[..., :3].view(np.uint32)).any())
         del nf_frame
         nearest = {"ms_per_step": round(float(np.median(ts)), 4), "same_frame_as_default": same,
-                   "note": "gpuart_hip_set_nearest_first(1024): the round-4 default (nearer child first + certificate, ~17 % fewer node visits), opt-in "
+                   "note": "gpuart_hip_set_nearest_first(1024): the round-4 default (nearer child first + certificate, ~17 %% fewer node visits), opt-in "
                            "since round 5 because the reference's phantom hits at grazing angles make any pruning walk in another order unprovable; "
                            "the same K passes, median of %d sequences; `same_frame_as_default`: its accumulator == the default walk's, bit for bit" % max(3, len(reps))}
 

@@ -80,29 +80,51 @@ inline uint32_t comm_timeout_ms() {
 
 /// Runs `fn` (which returns its rc and may fill a detail string) and waits at most timeout_ms for it. fn must own everything
 /// it touches through captured VALUES or objects that are never freed once the layer is stuck: it may outlive the caller's frame.
+/// One helper thread per process serves the calls (a gather makes two of them inside bench.py's timed region: starting a thread
+/// for each would cost a rank of an 8-GPU run a few per cent of its 3 ms); a helper whose call never returned is abandoned with
+/// it and the next call — the test hook's only: the real entry points refuse once the layer is stuck — gets a fresh one.
+struct Helper {
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(std::string &)> job;
+    unsigned long long posted = 0, done = 0;
+    int rc = 0;
+    std::string detail;
+};
+inline void helper_loop(std::shared_ptr<Helper> h) {
+    std::unique_lock<std::mutex> lk(h->m);
+    for (unsigned long long next = 1;; next++) {
+        h->cv_job.wait(lk, [&] { return h->posted >= next; });
+        std::function<int(std::string &)> fn = std::move(h->job);
+        lk.unlock();
+        std::string d;
+        const int rc = fn(d);
+        fn = nullptr;
+        lk.lock();
+        h->rc = rc; h->detail = std::move(d); h->done = next;
+        h->cv_done.notify_all();
+    }
+}
 inline Outcome bounded(const char *what, uint32_t timeout_ms, std::function<int(std::string &)> fn) {
     Outcome o;
     if (!timeout_ms) { o.rc = fn(o.detail); return o; }
-    struct Shared {
-        std::mutex m;
-        std::condition_variable cv;
-        bool done = false;
-        int rc = 0;
-        std::string detail;
-    };
-    auto sh = std::make_shared<Shared>();
-    std::thread([sh, fn]() {
-        std::string d;
-        const int rc = fn(d);
-        std::lock_guard<std::mutex> g(sh->m);
-        sh->rc = rc; sh->detail = std::move(d); sh->done = true;
-        sh->cv.notify_all();
-    }).detach();
-    std::unique_lock<std::mutex> lk(sh->m);
-    if (sh->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return sh->done; })) {
-        o.rc = sh->rc; o.detail = sh->detail;
+    static std::mutex callers;                    // one bounded call at a time (they are rare and their order matters to RCCL anyway)
+    static std::shared_ptr<Helper> *helper = new std::shared_ptr<Helper>();
+    std::lock_guard<std::mutex> one(callers);
+    if (!*helper) {
+        *helper = std::make_shared<Helper>();
+        std::thread(helper_loop, *helper).detach();
+    }
+    std::shared_ptr<Helper> h = *helper;
+    std::unique_lock<std::mutex> lk(h->m);
+    h->job = std::move(fn);
+    const unsigned long long mine = ++h->posted;
+    h->cv_job.notify_all();
+    if (h->cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return h->done >= mine; })) {
+        o.rc = h->rc; o.detail = h->detail;
         return o;
     }
+    helper->reset();  // that helper stays parked in the call (it keeps its own reference); it is never given another job
     o.timed_out = true;
     o.detail = std::string(what) + " has not returned after " + std::to_string(timeout_ms) + " ms (GPUART_HIP_COMM_TIMEOUT_MS); its thread stays "
                "parked in the call, the communicator layer of this process is out of service";

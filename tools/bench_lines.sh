@@ -15,7 +15,7 @@ import json
 for f in ["bench", "bench_driver_config", "bench_cfg2", "bench_cluster", "bench_tree", "bench_dragon871k", "bench_4k", "bench_steps1"]:
     d = json.loads(open("$OUT/%s.json" % f).read().strip().split("\n")[-1])
     r = d["roofline"]
-    print("%-20s %8.1f Mrays/s (reference-defined %8.1f)  %.4f ms/step  single %s  useful lanes %s = valu %s x lane_util %s  visits frac %s  L1 frac %s  traffic_frac %s  waves %s  cpu %s" % (
-        f, d["value"], d["mrays_reference_defined_per_s"], d["ms_per_step"], d["ms_per_frame_single"], r.get("frac"), r["valu_issue"].get("frac"),
+    print("%-20s %8.1f Mrays/s (reference-defined %8.1f)  %.4f ms/step  single %s  contract frac %s (algorithmic B per launch / launch time / 8 TB/s)  useful lanes %s = valu %s x lane_util %s  visits frac %s  L1 frac %s  traffic_frac %s  waves %s  cpu %s" % (
+        f, d["value"], d["mrays_reference_defined_per_s"], d["ms_per_step"], d["ms_per_frame_single"], r.get("frac"), (r.get("lane_slots") or {}).get("frac"), r["valu_issue"].get("frac"),
         r["valu_issue"].get("lane_util"), r["node_visits"].get("frac"), r["l1_accesses"].get("frac"), r["hbm"].get("traffic_frac"), r.get("k_trace_wave_states"), (d.get("cpu_baseline") or {}).get("value")))
 PY
