@@ -725,9 +725,16 @@ GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravSt
     } else if (GD_QUICK_BOXES && BOXES == GD_BOXES_FAST) {
         // the quick answer first (box_quick.h): it stands for all but a few boxes in 100 000; the lanes where one of the two is
         // withdrawn run the six face tests (a divergent region that the wave skips when no lane needs it)
+        // (the ray's slack is a pure function of the ray: the compiler computes it where the ray changes — the refill —, not per step)
         const float cs = gq_ray_slack(sc.box_slack, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, rdiv.x, rdiv.y, rdiv.z);
-        const bool sl = box_quick(r, rdiv, xyz(q0), xyz(q1), cs, el, hl);
-        const bool sh = box_quick(r, rdiv, xyz(q2), xyz(q3), cs, eh, hh);
+        // A ray the slack does not vet (NaN: a direction component of exactly 0 — every Sun-shadow ray of a Sun on the horizon, an
+        // axis-aligned camera ray —, a tiny origin component) has every quick answer withdrawn: a wave that holds only such rays does not
+        // run the quick tests at all (wave-uniform branch), a mixed wave runs them for the lanes that can use them.
+        bool sl = false, sh = false;
+        if (__ballot(cs == cs) != 0) {
+            sl = box_quick(r, rdiv, xyz(q0), xyz(q1), cs, el, hl);
+            sh = box_quick(r, rdiv, xyz(q2), xyz(q3), cs, eh, hh);
+        }
         bool ol = false, oh = false;
 #ifdef GD_QUICK_CHECK
         {

@@ -1712,6 +1712,18 @@ int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
     return 0;
 }
 
+#ifdef GD_STEP_STATS
+/// diagnostic builds only: reads (and clears) k_trace's step statistics (kernels_pipeline.h): box steps, lanes in them, leaf steps, lanes in
+/// them, rounds of the wide loop, lanes holding a ray in them, refill episodes
+int gpuart_hip_debug_step_stats(gpuart_hip_ctx *c, unsigned long long *out) {
+    if (!c || !out) return GPUART_HIP_ERR_ARG;
+    static unsigned long long zero[8];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_stats), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_step_stats), zero, sizeof(zero)));
+    return 0;
+}
+#endif
 #ifdef GD_QUICK_CHECK
 /// diagnostic builds only: reads (and clears) the counters of the quick box answers checked against the six face tests (device_scene.h)
 int gpuart_hip_debug_quick_stats(gpuart_hip_ctx *c, unsigned long long *out) {

@@ -31,6 +31,10 @@ struct TraceTuning {
 // =================================================================================================
 namespace {
 
+#ifdef GD_STEP_STATS
+__device__ unsigned long long g_step_stats[8];
+#endif
+
 /// Per-path state of one run of the wavefront pipeline: `batch` passes x `n_slots` pixel slots (pixel slot p: 8x8 tile
 /// p/64 of the tile in row-major tile order, pixel p%64 inside it), all arrays SoA and 16-byte aligned.
 /// Path slot s = pixel slot x batch + pass (slot_pass / slot_pixel_slot below): the passes of a run are INTERLEAVED per
@@ -335,9 +339,17 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     F3 rdiv = f3(1, 1, 1);
     Trav t; t.state = TRAV_DONE; t.closest = 0; t.hit_prim = GD_NO_PRIM; t.node = 0; t.entry = 0; t.second = 0;
 
+#ifdef GD_STEP_STATS
+    // diagnostic build (never the product): how full the wave's steps are — box steps and the lanes in them, leaf steps and the lanes in
+    // them, rounds of the wide loop and the lanes that hold a ray in them, refill episodes (tools/step_stats.py)
+    uint32_t ss_box = 0, ss_box_lanes = 0, ss_leaf = 0, ss_leaf_lanes = 0, ss_rounds = 0, ss_held = 0, ss_refills = 0;
+#endif
     for (;;) {
         // ---- refill idle lanes from the queue
         unsigned long long idle = __ballot(slot == SLOT_INVALID);
+#ifdef GD_STEP_STATS
+        ss_refills++;
+#endif
         while (idle && !exhausted) {
             if (chunk_next == chunk_end) {
                 if (static_end >= q_end) { exhausted = true; break; }
@@ -416,6 +428,9 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         } else
         // ---- traverse until enough lanes have finished (a lane without a ray is in state DONE)
         for (;;) {
+#ifdef GD_STEP_STATS
+            { const unsigned long long dd = __ballot(t.state == TRAV_DESCEND); if (dd) { ss_box++; ss_box_lanes += (uint32_t)__popcll(dd); } ss_rounds++; ss_held += (uint32_t)__popcll(__ballot(slot != SLOT_INVALID)); }
+#endif
             if (t.state == TRAV_DESCEND) trav_step_box<COUNT, GD_BOXES_OF(TYPES), NEAR>(sc, Ray{ro, rd}, rdiv, t, st, COUNT ? &wc : nullptr, !shadow && !refwalk);
             unsigned long long at_leaf = __ballot((t.state & 1) != 0);  // the leaf states are the odd ones
             unsigned long long descending = __ballot(t.state == TRAV_DESCEND);
@@ -423,6 +438,9 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             // a wave that is draining its last rays must not hold leaves back for a quorum it can no longer reach
             const uint32_t waiting = (uint32_t)__popcll(at_leaf);
             if (at_leaf && (waiting >= tune.leaf_lanes || tune.leaf_share * waiting >= waiting + (uint32_t)__popcll(descending))) {
+#ifdef GD_STEP_STATS
+                ss_leaf++; ss_leaf_lanes += waiting;
+#endif
                 if (t.state & 1) {
                     trav_step_leaf<false, COUNT, TYPES, NEAR>(sc, Ray{ro, rd}, t, st, COUNT ? &wc : nullptr, !shadow && !refwalk);
                     // the reference only asks a shadow query whether anything was hit: one accepted hit settles it
@@ -457,6 +475,12 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
         if (slot != SLOT_INVALID && t.state == TRAV_DONE) slot = SLOT_INVALID;
     }
     if (COUNT) flush_counters(wc, 0, gcounters);
+#ifdef GD_STEP_STATS
+    if (lane_id() == 0) {
+        const uint32_t v[7] = {ss_box, ss_box_lanes, ss_leaf, ss_leaf_lanes, ss_rounds, ss_held, ss_refills};
+        for (int k = 0; k < 7; k++) atomicAdd(&g_step_stats[k], (unsigned long long)v[k]);
+    }
+#endif
 }
 
 // ---- wavefront stage 2: shade segment `seg` of every path in queue[seg&1] (path_tracing.glsl:182-233) ---
