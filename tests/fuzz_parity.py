@@ -29,6 +29,11 @@ if RENDERER:
 WILD2 = "--wild2" in sys.argv  # the second class of hostile numbers (gpuart_amd.synth_scenes.random_wild2_case)
 if WILD2:
     sys.argv.remove("--wild2")
+SECONDS = None  # --seconds S: stop after S seconds and report the scenes that were done (a soak sized by time, not by count)
+if "--seconds" in sys.argv:
+    i = sys.argv.index("--seconds")
+    SECONDS = float(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 LATTICE = "--lattice" in sys.argv  # coplanar / coincident primitives on a coarse lattice (gpuart_amd.synth_scenes.random_lattice_case)
 if LATTICE:
     sys.argv.remove("--lattice")
@@ -46,7 +51,13 @@ def main():
         backends.append(B.Backend(0))
     os.environ["GPUART_HIP_NEAREST_MIN_PRIMS"] = "0"
     bad = 0
+    import time
+    t_end = time.time() + SECONDS if SECONDS else None
+    done = 0
     for seed in range(first, first + count):
+        if t_end and time.time() > t_end:
+            break
+        done += 1
         case = S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
         prims, W, H = case["prims"], case["W"], case["H"]
         cd = case["cam"]
@@ -144,7 +155,7 @@ def main():
         print("quick box answers: %.4g boxes, %.4f %% stand, %.3f %% of the steps ran the face tests, %d standing answers differ from them"
               % (ev[0], 100.0 * ev[1] / max(1, ev[0]), 100.0 * ev[3] / max(1, ev[2]), ev[4]))
         bad += int(ev[4])
-    print("fuzz: %d scenes, %d with differences" % (count, bad))
+    print("fuzz: %d scenes, %d with differences" % (done, bad))
     return 1 if bad else 0
 
 
