@@ -168,6 +168,16 @@ def cam_rays(cam, W, H):
     return rs, rd
 
 
+def first_segment_rays(cam, W, H, P, rand_seed, j=0):
+    """(rstart, rdir) (H, W, 4) of path j's first segment of every pixel: the jittered camera rays of a path-tracing pass."""
+    rs = np.zeros((H, W, 4), np.float32)
+    rd = np.zeros((H, W, 4), np.float32)
+    cam = np.ascontiguousarray(cam, np.float32)
+    rsd = (C.c_float * 4)(*[float(x) for x in rand_seed])
+    lib().orc_first_segment_rays(_p(cam), W, H, C.byref(P), rsd, C.c_int(j), _p(rs), _p(rd))
+    return rs, rd
+
+
 def pixel_uv(xy, W, H):
     xy = np.ascontiguousarray(xy, np.int32)
     out = np.zeros((xy.shape[0], 2), np.float32)

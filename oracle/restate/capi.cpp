@@ -198,6 +198,20 @@ void orc_cam_rays(const float *cam, int W, int H, float *rstart, float *rdir) {
         }
 }
 
+/// The ray of path j's first segment of every pixel (path_tracing.glsl:141-175: the camera ray, jittered): what the path tracer's first
+/// closest-hit query of a pass is asked — for tests that aim such a ray at something (tests/golden/make_golden.py order_adversary_frames).
+void orc_first_segment_rays(const float *cam, int W, int H, const Params *P, const float *randSeed, int j, float *rstart, float *rdir) {
+    FtzDaz ftz_guard;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            V3 s0, d0, s, d;
+            CamInitPixel(x, y, W, H, cam, cam + 3, cam + 6, cam + 9, s0, d0);
+            FirstSegmentRay(s0, d0, *P, randSeed, j, s, d);
+            out4(rstart, y * W + x, s.x, s.y, s.z, 0);
+            out4(rdir, y * W + x, d.x, d.y, d.z, 0);
+        }
+}
+
 /// UV of selected pixels: xy = n x (int x, int y); out = n x 2 floats.
 void orc_pixel_uv(const int *xy, int n, int W, int H, float *out) {
     FtzDaz ftz_guard;

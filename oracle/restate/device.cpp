@@ -459,11 +459,8 @@ V3 DirectLightingPixel(V3 rstart, V3 rdir, const float *tree, const Params &P, T
 }
 
 // ---- path_tracing.glsl:133-256 -----------------------------------------------------------
-V3 PathTracingPixel(V3 rstart0, V3 rdir0, const float *tree, const Params &P, const float rsd[4], int npaths,
-                    TravStats *st, uint64_t *nseg) {
-    const float FUZZY_ANGLE = 10 * 3.14159f / 180;
-    V3 sun{P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]};
-    V3 seed{rsd[0], rsd[1], rsd[2]};
+// path_tracing.glsl:141-175: the jittered ray of path j's first segment (also exported for the tests that aim a camera ray: capi.cpp)
+void FirstSegmentRay(V3 rstart0, V3 rdir0, const Params &P, const float rsd[4], int j, V3 &rstart, V3 &rdir) {
     V3 camPos{P.cameraPos[0], P.cameraPos[1], P.cameraPos[2]};
     V3 o1;
     if (fabsf(rdir0.x) > 1.0e-5f || fabsf(rdir0.y) > 1.0e-5f)
@@ -471,12 +468,21 @@ V3 PathTracingPixel(V3 rstart0, V3 rdir0, const float *tree, const Params &P, co
     else
         o1 = normalize3(V3{0, -rdir0.z, rdir0.y});
     V3 o2 = cross3(normalize3(rdir0), o1);
+    float rand1 = random1(rsd[0] + (float)j);
+    float rand2 = random1(rsd[1] + (float)j);
+    rstart = (rstart0 + ((rand1 - 0.5f) * o1) * P.pixelSize) + ((rand2 - 0.5f) * o2) * P.pixelSize;
+    rdir = rstart - camPos;
+}
+
+V3 PathTracingPixel(V3 rstart0, V3 rdir0, const float *tree, const Params &P, const float rsd[4], int npaths,
+                    TravStats *st, uint64_t *nseg) {
+    const float FUZZY_ANGLE = 10 * 3.14159f / 180;
+    V3 sun{P.sunDirAlt[0], P.sunDirAlt[1], P.sunDirAlt[2]};
+    V3 seed{rsd[0], rsd[1], rsd[2]};
     V3 color{0, 0, 0};
     for (int j = 0; j < npaths; j++) {
-        float rand1 = random1(rsd[0] + (float)j);
-        float rand2 = random1(rsd[1] + (float)j);
-        V3 rstart = (rstart0 + ((rand1 - 0.5f) * o1) * P.pixelSize) + ((rand2 - 0.5f) * o2) * P.pixelSize;
-        V3 rdir = rstart - camPos;
+        V3 rstart, rdir;
+        FirstSegmentRay(rstart0, rdir0, P, rsd, j, rstart, rdir);
         V3 pathColor{0, 0, 0}, cw{1, 1, 1};
         bool ush = false, specular = false;
         int i;

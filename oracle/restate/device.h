@@ -95,6 +95,7 @@ void CamInitPixel(int x, int y, int W, int H, const float pos[3], const float bl
 // direct_lighting.glsl:134-207
 V3 DirectLightingPixel(V3 rstart, V3 rdir, const float *tree, const Params &P, TravStats *st);
 // path_tracing.glsl:133-256 (returns the sum over npaths paths, to be added to PrevRadiance)
+void FirstSegmentRay(V3 rstart0, V3 rdir0, const Params &P, const float randSeed[4], int j, V3 &rstart, V3 &rdir);
 V3 PathTracingPixel(V3 rstart0, V3 rdir0, const float *tree, const Params &P, const float randSeed[4],
                     int npaths, TravStats *st, uint64_t *npaths_segments);
 

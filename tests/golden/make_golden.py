@@ -914,8 +914,87 @@ def gen_order_adversary(gl):
     save("order_adversary", n=len(cases) // 6, **cases)
 
 
+def gen_order_adversary_frames(gl):
+    """tests/golden/order_adversary_frame_*.npz: the phantom hit of gen_order_adversary END TO END, through the reference's path-tracing
+    program. A small frame with the default camera; the first-segment ray of one pixel (the jittered camera ray, path_tracing.glsl:141-175,
+    from the oracle's restatement) is the ray a triangle is laid under at a grazing angle until the reference's intersector returns a
+    phantom; a disc between phantom and triangle, two fillers. The reference's own programs render the frame: the pixel shows the TRIANGLE
+    (its phantom), a walk that prunes in another order shows the disc. Expected values: the reference's GLSL (pt pass 1 + accumulation of 2)."""
+    f32 = np.float32
+    rng = np.random.RandomState(20261006)
+    progs = RefPrograms(gl)
+    W, H = 24, 16
+    camd = default_cam()
+    cam = O.camera(camd["pos"], camd["dir"], camd["up"], camd["fov_y"], camd["screen_dist"], W, H)
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], 5, 0.01)
+    seeds = O.randseeds(2)
+    rs_all, rd_all = O.first_segment_rays(cam, W, H, P, seeds[0], 0)
+    made = 0
+    for attempt in range(4000):
+        if made >= 3:
+            break
+        px, py = int(rng.randint(4, W - 4)), int(rng.randint(4, H - 4))
+        o, d = rs_all[py, px, :3].copy(), rd_all[py, px, :3].copy()
+        u = d.astype(np.float64) / np.linalg.norm(d)
+        a = np.cross(u, rng.normal(size=3)); a /= np.linalg.norm(a)
+        b = np.cross(u, a)
+        n = 60000
+        eps = 10 ** rng.uniform(-6.5, -5, n); s_ = 10 ** rng.uniform(-1.3, -0.5, n); Ld = rng.uniform(1.0, 3.0, n); a0 = rng.uniform(0.25, 0.55, n)
+        phi = rng.uniform(0, 2 * np.pi, n)
+        v = np.cos(phi)[:, None] * a + np.sin(phi)[:, None] * b
+        w = -np.sin(phi)[:, None] * a + np.cos(phi)[:, None] * b
+        loc = np.array([[0.0, -0.4], [1.0, -0.1], [0.3, 0.6]])
+        V = np.zeros((n, 3, 3))
+        for k in range(3):
+            al, be = loc[k, 0] * s_, loc[k, 1] * s_
+            hgt = eps * (al - a0 * s_)
+            V[:, k, :] = o.astype(np.float64) + u * (Ld + al)[:, None] + v * be[:, None] + w * hgt[:, None]
+        V = V.astype(f32)
+        O4, D4 = np.tile(pad4(o[None]), (n, 1)), np.tile(pad4(d[None]), (n, 1))
+        t = O.triangle(O4, D4, pad4(V[:, 0]), pad4(V[:, 1]), pad4(V[:, 2]))[0][:, 0]
+        bx = O.aabb(O4, D4, pad4(V.min(1)), pad4(V.max(1)))
+        bad = np.flatnonzero((t > 0) & (bx[:, 0] > 0) & (bx[:, 1] > 0) & (t * 1.05 < bx[:, 1]))
+        if not len(bad):
+            continue
+        k = bad[np.argmax(bx[bad, 1] / t[bad])]
+        Vt, tp, eT = V[k], t[k], bx[k, 1]
+        for _ in range(30):
+            tS = f32(rng.uniform(tp * 1.002, eT / 1.01))
+            cS = o.astype(np.float64) + tS * d.astype(np.float64)
+            tri = lambda cc, sz: (2, list((cc + rng.normal(size=3) * sz)) + list((cc + rng.normal(size=3) * sz)) + list((cc + rng.normal(size=3) * sz)))
+            prims = [(2, list(Vt.reshape(-1).astype(float))), tri(Vt.mean(0) + rng.normal(size=3) * 0.3, 0.01),
+                     (1, list(cS) + list(u) + [float(rng.uniform(0.01, 0.04))]), tri(cS + rng.normal(size=3) * 0.3, 0.01)]
+            tree, _ = O.build_bvh(prims)
+            r0, r1 = O.traverse(tree, pad4(o[None]), pad4(d[None]), (0, 0, 0, 0))
+            cl, win, again = _nf_walk(_nf_parse(tree), o, d)
+            if not (r1[0, 3] == 2.0 and win is not None and r0[0, 0] != cl and not again):
+                continue
+            r = RefRenderer(gl, progs, W, H, camd, tree)
+            r.us = (S.USER_SPHERE[0], S.USER_SPHERE[1], S.USER_SPHERE[2], 0.0)
+            p1 = r.pt_pass(1, seeds[0])[..., :3].copy()
+            acc = r.pt_pass(1, seeds[1])[..., :3].copy()
+            # the oracle's frame must be the reference's, and the pixel must be the triangle's: re-render with the triangle removed — the disc shows
+            acc_o = np.zeros((H, W, 4), f32)
+            O.pt_pass(tree, cam, W, H, P, seeds[0], 1, acc_o)
+            if not (acc_o[..., :3].view(np.uint32) == p1.view(np.uint32)).all():
+                print("order_adversary_frames: oracle != reference on a candidate (kept out; investigate)"); continue
+            tree2, _ = O.build_bvh(prims[1:])
+            acc2 = np.zeros((H, W, 4), f32)
+            O.pt_pass(tree2, cam, W, H, P, seeds[0], 1, acc2)
+            if (acc2[py, px, :3].view(np.uint32) == p1[py, px].view(np.uint32)).all():
+                continue  # (the pixel looks the same with and without the triangle: not a visible phantom)
+            save("order_adversary_frame_%d" % made, tree=tree, W=W, H=H, cam=cam, seeds=seeds, max_segments=5, pixel=np.array([px, py]),
+                 pt_pass1=p1, pt_acc=acc, nearest_first_t=f32(cl), reference_t=r0[0, 0])
+            print("order_adversary_frame_%d: pixel (%d, %d): the reference's first query returns the triangle's phantom at t = %.6f, a nearest-first walk the disc at %.6f"
+                  % (made, px, py, r0[0, 0], cl))
+            made += 1
+            break
+    assert made == 3, made
+
+
 SECTIONS = dict(dragon871k=gen_dragon871k, lattice=gen_lattice, scene_p=gen_scene_p, cluster_tree=gen_cluster_tree, hash=gen_hash, llvmpipe_math=gen_llvmpipe_math, hemisphere=gen_hemisphere, sphere=gen_sphere,
-                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, order_rays=gen_order_rays, order_adversary=gen_order_adversary, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
+                disc=gen_disc, triangle=gen_triangle, cone=gen_cone, aabb=gen_aabb, aabb_irregular=gen_aabb_irregular, intersect_wild=gen_intersect_wild, shade_wild=gen_shade_wild, traverse_wild=gen_traverse_wild, traverse_leaves=gen_traverse_leaves, order_rays=gen_order_rays, order_adversary=gen_order_adversary, order_adversary_frames=gen_order_adversary_frames, sky=gen_sky, uv=gen_uv, camrays=gen_camrays,
                 traverse=gen_traverse, frames=gen_frames, fuzz=gen_fuzz, fullsize=gen_fullsize)
 
 if __name__ == "__main__":

@@ -401,6 +401,46 @@ def test_phantom_hits_are_why_nearest_first_is_opt_in(be, B, O):
     assert differing == n, "the nearest-first walk now agrees with the reference on %d of %d phantom hits: re-examine why it is opt-in" % (n - differing, n)
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_phantom_hits_in_whole_frames(B, O, k):
+    """tests/golden/order_adversary_frame_k.npz: the phantom hit through the PRODUCT's render kernels. One pixel's first-segment ray grazes a
+    triangle; the reference's own path-tracing program (the fixture) shows the triangle's phantom in that pixel, in front of the disc that
+    stands before the triangle. The default walks — launch pipeline, k_run, megakernel: modes 0 / 3 / 5 / 2 — must render the reference's
+    frames bit for bit; with the nearest-first walk opted in the pixel shows something else (and only the reference-order megakernel,
+    mode 2, still shows the reference's) — which is why it is opt-in."""
+    g = golden("order_adversary_frame_%d" % k)
+    W, H = int(g["W"]), int(g["H"])
+    cam, tree, seeds = g["cam"], g["tree"], g["seeds"]
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], int(g["max_segments"]), 0.01)
+    px, py = (int(v) for v in g["pixel"])
+    b = B.Backend(0)
+    try:
+        b.resize(W, H); b.upload_bvh(tree); b.set_camera(cam)
+        b.set_nearest_first(0xffffffff)            # the product's default, whatever the suite's environment says
+        assert b.scene_order() == 1
+        for mode in (0, 3, 5, 2):
+            b.set_mode(mode)
+            b.pt_reset()
+            b.pt_pass(to_params(B, P), seeds[0], 1)
+            assert_bits(b.read(1)[..., :3].reshape(-1, 3), g["pt_pass1"].reshape(-1, 3), "adversary frame %d, first pass, mode %d" % (k, mode))
+            b.pt_pass(to_params(B, P), seeds[1], 1)
+            assert_bits(b.read(1)[..., :3].reshape(-1, 3), g["pt_acc"].reshape(-1, 3), "adversary frame %d, two passes, mode %d" % (k, mode))
+        b.set_nearest_first(0)                     # opt in, on this small tree too
+        assert b.scene_order() == 0
+        for mode in (0, 3, 5):
+            b.set_mode(mode)
+            b.pt_reset()
+            b.pt_pass(to_params(B, P), seeds[0], 1)
+            got = b.read(1)[..., :3]
+            assert (got[py, px].view(np.uint32) != g["pt_pass1"][py, px].view(np.uint32)).any(), "mode %d: the opt-in walk shows the phantom too?" % mode
+            others = np.ones((H, W), bool); others[py, px] = False
+            assert_bits(got[others], g["pt_pass1"][others], "adversary frame %d, opt-in walk, every OTHER pixel, mode %d" % (k, mode))
+        b.set_mode(0)
+    finally:
+        b.close()
+
+
 def test_rays_on_which_visiting_order_decides(be, O):
     """Four rays found by tools/order_rays.py among 1.7e9 (tests/golden/order_rays.npz): each meets a box whose entry parameter, as
     the reference computes it, is NOT its slab entry — the face the ray enters through fails its own test by rounding at an

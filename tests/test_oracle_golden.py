@@ -239,6 +239,28 @@ def test_phantom_hits_of_grazing_triangles():
         assert o1[0, 3] == 2.0 and o0[0, 0] < g["nf%d" % i]  # the triangle wins, in front of what a nearest-first walk finds
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_phantom_hits_in_whole_frames(k):
+    """tests/golden/order_adversary_frame_k.npz (make_golden.py order_adversary_frames): the phantom hit end to end. The first-segment ray of
+    one pixel of a 24x16 frame grazes a triangle laid under it; the reference's own path-tracing program shows the triangle's phantom in that
+    pixel although a disc stands in front of the triangle. The oracle's passes must be the reference's frames bit for bit, and its first
+    query of that pixel must return the phantom."""
+    g = golden("order_adversary_frame_%d" % k)
+    W, H = int(g["W"]), int(g["H"])
+    cam, tree, seeds = g["cam"], g["tree"], g["seeds"]
+    sun = O.sun_direction(S.SUN_AZIMUTH, S.SUN_ALTITUDE)
+    P = O.make_params(sun, S.SUN_ALTITUDE, True, S.USER_SPHERE, 0.0, 0, float(cam[12]), cam[0:3], int(g["max_segments"]), 0.01)
+    acc = np.zeros((H, W, 4), np.float32)
+    O.pt_pass(tree, cam, W, H, P, seeds[0], 1, acc)
+    assert_bits(acc[..., :3].reshape(-1, 3), g["pt_pass1"].reshape(-1, 3), "first pass")
+    O.pt_pass(tree, cam, W, H, P, seeds[1], 1, acc)
+    assert_bits(acc[..., :3].reshape(-1, 3), g["pt_acc"].reshape(-1, 3), "two passes accumulated")
+    px, py = (int(v) for v in g["pixel"])
+    rs, rd = O.first_segment_rays(cam, W, H, P, seeds[0], 0)
+    o0, o1 = O.traverse(tree, rs[py, px][None], rd[py, px][None], (0, 0, 0, 0))
+    assert o1[0, 3] == 2.0 and o0[0, 0] == g["reference_t"] and o0[0, 0] < g["nearest_first_t"]
+
+
 FRAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "frames_*.npz")))
 
 
