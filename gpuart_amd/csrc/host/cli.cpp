@@ -23,7 +23,8 @@ static void usage() {
     std::cerr << "usage: gpuart_cli [--scene box|ply:<file>|cluster|tree] [--width W] [--height H] [--mode direct|pt]\n"
                  "                  [--spp N] [--per-pass K] [--max-segments M] [--seed S] [--tile x0,y0,w,h]\n"
                  "                  [--camera px,py,pz] [--sun az,alt[,off]] [--user-sphere x,y,z,r,em[,specular[,fuzzy]]]\n"
-                 "                  [--device D] [--gpus N] [--resume ck] [--checkpoint ck] [--pfm out.pfm] [--ppm out.ppm]\n"
+                 "                  [--device D] [--gpus N] [--resume ck] [--checkpoint ck] [--pfm out.pfm] [--ppm out.ppm] [--nearest-first]\n"
+                 "  --nearest-first: opt in to the nearer-child-first BVH walk (~10 % faster; soak-verified, not proven to be the reference's image)\n"
                  "  --gpus N: path tracing of ONE frame on devices D..D+N-1 (8-row bands dealt round-robin, gathered over RCCL)\n";
 }
 
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
     std::string scene = "box", mode = "pt", pfm, ppm, resume, checkpoint;
     unsigned W = 640, H = 480, spp = 16, perPass = 1, maxSeg = 5, device = 0, gpus = 1;
     long seed = -1;
+    bool nearestFirst = false;
     float tile[4] = {0, 0, 0, 0}, campos[3] = {0.1f, -3.05f, 1.0f}, sun[3] = {0, 0, 0}, us[7] = {-0.4f, 0, 0.2f, 0, 0, 0, 0};
     int nTile = 0, nSun = 0, nUs = 0, n;
     for (int i = 1; i < argc; i++) {
@@ -68,6 +70,7 @@ int main(int argc, char **argv) {
         else if (a == "--ppm") ppm = need("--ppm");
         else if (a == "--resume") resume = need("--resume");
         else if (a == "--checkpoint") checkpoint = need("--checkpoint");
+        else if (a == "--nearest-first") nearestFirst = true;
         else { usage(); return 2; }
     }
     if (W == 0 || H == 0 || (mode != "direct" && mode != "pt")) { usage(); return 2; }
@@ -95,6 +98,7 @@ int main(int argc, char **argv) {
         if (nSun >= 2) { r.SetSunAzimuth(sun[0]); r.SetSunAltitude(sun[1]); if (nSun == 3) r.SetSunDirectLighting(sun[2] == 0); }
         r.SetMaxPathSegments(maxSeg);
         if (seed >= 0) r.SetSeed((uint32_t)seed);
+        if (nearestFirst && !r.SetNearestFirst(1024)) return 1;
         if (scene == "box") InitBox(r);
         else if (scene.compare(0, 4, "ply:") == 0) ok = InitDragon(r, scene.c_str() + 4);
         else if (scene.compare(0, 8, "cluster:") == 0) ok = InitCluster(r, scene.c_str() + 8);

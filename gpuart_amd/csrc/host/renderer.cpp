@@ -107,6 +107,13 @@ bool Renderer::SetInterleavedTile(unsigned x0, unsigned y0, unsigned w, unsigned
     return true;
 }
 
+bool Renderer::SetNearestFirst(uint32_t minPrims) {
+    if (!Backend) return false;
+    if (!Check(gpuart_hip_set_nearest_first(Backend, minPrims), "choosing the visiting order")) return false;
+    ResetPathTracing();
+    return true;
+}
+
 bool Renderer::SetShare(int rank, int nranks) {
     if (!Backend) return false;
     gpuart_tile_geom g;

@@ -88,6 +88,10 @@ public:
     void SetMaxPathSegments(unsigned n) { MaxPathSegments = n; ResetPathTracing(); }
     void SetMinWeight(float w) { MinWeight = w; ResetPathTracing(); }
     void SetSeed(uint32_t seed) { RndGen.seed(seed); ResetPathTracing(); }
+    /// Opts in to the nearer-child-first BVH walk for trees of at least minPrims primitives (0xffffffff = never, the default): ~10 % faster,
+    /// soak-verified but NOT proven to return the reference's winner — the reference's phantom hits of grazing triangles are a property
+    /// of its own visiting order (include/gpuart_hip.h gpuart_hip_set_nearest_first). Restarts the accumulation like every setter.
+    bool SetNearestFirst(uint32_t minPrims);
     /// Restricts this renderer to a tile of the frame (screen-space sharding across GPUs).
     bool SetTile(unsigned x0, unsigned y0, unsigned w, unsigned h);
     /// Row bands interleaved with other renderers (rank r of N: y0 = bandRows*r, bandStride = bandRows*N).
