@@ -191,7 +191,10 @@ int wait_stream(gpuart_hip_ctx *c, uint32_t timeout_ms, const char *what) {
             return fail(GPUART_HIP_ERR_TIMEOUT, std::string(what) + ": not complete after " + std::to_string(timeout_ms) +
                         " ms (rank " + std::to_string(c->comm_rank) + " of " + std::to_string(c->comm_nranks) + "; a peer has not joined the collective)");
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        // (a gather's waits sit inside bench.py's timed region, where a rank's whole job is ~3 ms at N = 8: the first few milliseconds are
+        //  polled without sleeping — a sleep of 50 us returns after 100-150 —, a wait that lasts longer is not in a hurry)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else std::this_thread::yield();
     }
 }
 }  // namespace
