@@ -300,6 +300,21 @@ def main():
         except Exception:  # noqa: BLE001
             store = None
     gather_seq = [0]
+    # a rank's arrival at gather #n is recorded in the rendezvous store by a helper thread: the TCP round trip of store.set (~0.1 ms) stays
+    # out of the timed region, where a rank's whole job is ~3 ms at N = 8
+    import queue
+    import threading
+    arrivals = queue.Queue()
+
+    def _announce():
+        while True:
+            key = arrivals.get()
+            try:
+                store.set(key, "1")
+            except Exception:  # noqa: BLE001
+                pass
+    if store is not None:
+        threading.Thread(target=_announce, daemon=True).start()
 
     def missing_ranks(tag):
         if store is None:
@@ -321,7 +336,7 @@ def main():
         gather_seq[0] += 1
         tag = str(gather_seq[0])
         if store is not None:
-            store.set("gpuart_arrived_%s_%d" % (tag, rank), "1")
+            arrivals.put("gpuart_arrived_%s_%d" % (tag, rank))
         if gather_note is None:
             try:
                 with phase("frame gather #%s (gpuart_hip_gather + gpuart_hip_wait)" % tag, int(args.gather_timeout * 1000) + phase_ms):
