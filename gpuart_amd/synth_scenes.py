@@ -265,6 +265,60 @@ def random_lattice_case(seed):
     return case
 
 
+def random_grazing_case(seed):
+    """Fifth fuzz class (round 5, `--grazing`): frames full of rays that GRAZE triangles — the regime in which the reference's
+    Moeller-Trumbore (shaders/triangle.glsl:50-76) divides two cancelled sums and accepts phantom hits far from the triangle. A fan of
+    triangulated sheets, each in a plane that (almost) contains the camera position — like the pages of a book seen from its spine —,
+    spread over a narrow vertical field of view so that every pixel row runs along some sheet; any orientation (a third of the cases
+    axis-aligned), a little off-plane noise per vertex; discs across the view and spheres stand between the sheets, so that there are
+    surfaces between phantoms and their triangles' boxes. What the reference renders here is a property of its own visiting order
+    (csrc/hip/device_scene.h): the class soaks the reference-order walks, and the oracle itself against the reference's GLSL
+    (tests/golden/soak_oracle_vs_reference.py --grazing)."""
+    case = random_case(seed)
+    rs = np.random.RandomState(5000011 + seed)
+    if rs.rand() < 0.33:
+        k = rs.randint(3)
+        n = np.eye(3)[k]; u = np.eye(3)[(k + 1) % 3]; v = np.eye(3)[(k + 2) % 3]
+    else:
+        n = rs.normal(size=3); n /= np.linalg.norm(n)
+        u = np.cross(n, rs.normal(size=3)); u /= np.linalg.norm(u)
+        v = np.cross(n, u)
+    pos = rs.uniform(-0.5, 0.5, 3)
+    fov = float(rs.choice([1.0, 3.0, 10.0, 40.0]))
+    sheets = int(rs.choice([1, 4, 16, 40]))
+    m = int(rs.choice([1, 2, 4]))
+    size = float(rs.uniform(0.3, 1.5))
+    noise = float(rs.choice([0.0, 1e-7, 1e-6, 1e-5]))
+    prims = []
+    for _ in range(sheets):
+        th = np.radians(rs.uniform(-0.5, 0.5) * fov)
+        uk = np.cos(th) * u + np.sin(th) * n            # the sheet's plane contains v and uk; its normal nk
+        nk = np.cos(th) * n - np.sin(th) * u
+        c0 = pos + uk * rs.uniform(0.3, 2.0) + nk * (float(rs.choice([0.0, 1e-6, 1e-5, 1e-4])) * float(rs.choice([-1, 1])))
+        grid = np.zeros((m + 1, m + 1, 3))
+        for i in range(m + 1):
+            for j in range(m + 1):
+                grid[i, j] = c0 + uk * (size * i / m) + v * (size * (2.0 * j / m - 1.0)) + nk * (noise * rs.uniform(-1, 1))
+        for i in range(m):
+            for j in range(m):
+                a, b, cc, d = grid[i, j], grid[i + 1, j], grid[i + 1, j + 1], grid[i, j + 1]
+                prims.append((TRIANGLE, [f32(x) for x in np.concatenate([a, b, cc])]))
+                prims.append((TRIANGLE, [f32(x) for x in np.concatenate([a, cc, d])]))
+    for _ in range(int(rs.choice([0, 2, 6, 16]))):   # discs across the view, spheres between the sheets
+        th = np.radians(rs.uniform(-0.5, 0.5) * fov)
+        q = pos + (np.cos(th) * u + np.sin(th) * n) * rs.uniform(0.3, 2.5) + v * rs.uniform(-size, size)
+        if rs.rand() < 0.6:
+            prims.append((DISC, [f32(q[0]), f32(q[1]), f32(q[2]), f32(u[0]), f32(u[1]), f32(u[2]), f32(rs.uniform(0.002, 0.1))]))
+        else:
+            prims.append((SPHERE, [f32(q[0]), f32(q[1]), f32(q[2]), f32(rs.uniform(0.002, 0.08))]))
+    case["prims"] = prims
+    case["cam"] = dict(pos=tuple(float(f32(x)) for x in pos), dir=tuple(float(f32(x)) for x in u), up=tuple(float(f32(x)) for x in n),
+                       fov_y=float(f32(fov)), screen_dist=0.2)
+    case["us_flags"], case["us_em"] = 0, 0.0
+    case["user_sphere"] = (case["user_sphere"][0], case["user_sphere"][1], case["user_sphere"][2], 0.0)
+    return case
+
+
 # ---- stand-ins for the reference's two primitive-list scenes (data/cluster_100k.dat, data/tree1_21k.dat are absent) ----
 # Written in the dialect Utils::LoadPrimitives reads (src/utils.cpp:136-203): `sphere x y z [r]` (r defaults to 4) and
 # `cone x1 y1 z1 x2 y2 z2 r1 r2` lines, `#` comments; loaded as InitCluster / InitTree do (src/scenes.cpp:69-103).

@@ -29,6 +29,9 @@ if RENDERER:
 WILD2 = "--wild2" in sys.argv  # the second class of hostile numbers (gpuart_amd.synth_scenes.random_wild2_case)
 if WILD2:
     sys.argv.remove("--wild2")
+GRAZING = "--grazing" in sys.argv  # frames full of rays that graze triangles: the reference's phantom hits (synth_scenes.random_grazing_case). The product's
+if GRAZING:                        # default (reference-order walks) must equal the oracle; the opt-in nearest-first walk is rendered too, and the scenes on
+    sys.argv.remove("--grazing")   # which it differs are COUNTED, not failed: it is opt-in precisely because it cannot reproduce phantom hits
 SECONDS = None  # --seconds S: stop after S seconds and report the scenes that were done (a soak sized by time, not by count)
 if "--seconds" in sys.argv:
     i = sys.argv.index("--seconds")
@@ -42,8 +45,8 @@ if LATTICE:
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    # two contexts: one that walks every regular tree nearer child first (the kernels of the big scenes), one with the library's
-    # default (trees this small keep the reference's order): every scene goes through both
+    # two contexts: one that walks every regular tree nearer child first (the opt-in kernels, GPUART_HIP_NEAREST_MIN_PRIMS=0), one with the
+    # library's default (every walk in the reference's order): every scene goes through both
     backends = []
     for knob in ("0", None):
         if knob is None: os.environ.pop("GPUART_HIP_NEAREST_MIN_PRIMS", None)
@@ -51,6 +54,7 @@ def main():
         backends.append(B.Backend(0))
     os.environ["GPUART_HIP_NEAREST_MIN_PRIMS"] = "0"
     bad = 0
+    nf_scenes = 0
     import time
     t_end = time.time() + SECONDS if SECONDS else None
     done = 0
@@ -58,7 +62,7 @@ def main():
         if t_end and time.time() > t_end:
             break
         done += 1
-        case = S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
+        case = S.random_grazing_case(seed) if GRAZING else S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
         prims, W, H = case["prims"], case["W"], case["H"]
         cd = case["cam"]
         cam = O.camera(cd["pos"], cd["dir"], cd["up"], cd["fov_y"], cd["screen_dist"], W, H)
@@ -132,15 +136,20 @@ def main():
                     res["pt", mode + 10 * which] = be.read(1)
                 be.set_mode(0)
         ok = True
+        nf_differs = False
         for (what, mode), got in res.items():
             exp = exp_direct if what == "direct" else acc
             same = (got[..., :3].view(np.uint32) == exp[..., :3].view(np.uint32)) | ((got[..., :3] == 0) & (exp[..., :3] == 0)) \
                 | (np.isnan(got[..., :3]) & np.isnan(exp[..., :3]))
+            if not same.all() and GRAZING and what == "pt" and mode < 10 and mode % 10 != 2:
+                nf_differs = True  # (the first context walks nearest-first in modes 0 / 3; mode 2, the megakernel, keeps the reference's order)
+                continue
             if not same.all():
                 ok = False
                 print("seed %d: %s mode %d%s: %d of %d pixels differ (%d prims, %dx%d, flags %d)"
                       % (seed, what, mode % 10, " (default visiting order)" if mode >= 10 else "", int((~same.all(-1)).sum()), W * H, len(prims), W, H, flags), flush=True)
         bad += 0 if ok else 1
+        nf_scenes += 1 if nf_differs else 0
     for be in backends:
         be.close()
     # a library built with -DGD_QUICK_CHECK (tools/ab_build.sh qcheck ..., GPUART_LIBDIR) has run every fast-form box test of these scenes
@@ -155,6 +164,8 @@ def main():
         print("quick box answers: %.4g boxes, %.4f %% stand, %.3f %% of the steps ran the face tests, %d standing answers differ from them"
               % (ev[0], 100.0 * ev[1] / max(1, ev[0]), 100.0 * ev[3] / max(1, ev[2]), ev[4]))
         bad += int(ev[4])
+    if GRAZING:
+        print("(opt-in nearest-first walk: %d of these scenes differ from the reference — phantom hits it does not test; counted, not failed)" % nf_scenes)
     print("fuzz: %d scenes, %d with differences" % (done, bad))
     return 1 if bad else 0
 

@@ -26,13 +26,18 @@ if LATTICE:
     sys.argv.remove("--lattice")
 
 
+GRAZING = "--grazing" in sys.argv  # frames full of rays that graze triangles: the phantom hits of shaders/triangle.glsl:50-76 (synth_scenes.random_grazing_case)
+if GRAZING:
+    sys.argv.remove("--grazing")
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     gl = glref.GLRef()
     progs, bad = {}, 0
     for seed in range(first, first + count):
-        case = S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
+        case = S.random_grazing_case(seed) if GRAZING else S.random_lattice_case(seed) if LATTICE else S.random_wild2_case(seed) if WILD2 else S.random_wild_case(seed) if WILD else S.random_case(seed)
         tree, _ = O.build_bvh(case["prims"])
         ms = case["max_segments"]
         if ms not in progs:
