@@ -60,6 +60,20 @@ inline std::string recent_errors() {
     return s;
 }
 
+/// cv.wait_for(lk, timeout, pred) on the STEADY clock, in slices of at most 100 ms of pthread_cond_timedwait (system clock): a wall-clock
+/// jump costs one slice, not the bound — and the sanitizers of this toolchain intercept pthread_cond_timedwait but not the
+/// pthread_cond_clockwait that std::condition_variable::wait_for(steady) compiles to (tools/sanitize_bounded.sh would drown in false reports).
+template <class Pred>
+inline bool wait_steady(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, double seconds, Pred pred) {
+    const double end = now_s() + seconds;
+    while (!pred()) {
+        const double left = end - now_s();
+        if (left <= 0) return false;
+        cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(std::chrono::duration<double>(left < 0.1 ? left : 0.1)));
+    }
+    return true;
+}
+
 // ---- calls that cannot be given a timeout, run beside a bounded wait ---------------------------------------------------------
 inline std::atomic<bool> &stuck() { static std::atomic<bool> s{false}; return s; }
 inline std::string &stuck_in() { static std::string *s = new std::string(); return *s; }  // written once, before stuck() is set
@@ -120,7 +134,7 @@ inline Outcome bounded(const char *what, uint32_t timeout_ms, std::function<int(
     h->job = std::move(fn);
     const unsigned long long mine = ++h->posted;
     h->cv_job.notify_all();
-    if (h->cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return h->done >= mine; })) {
+    if (wait_steady(h->cv_done, lk, timeout_ms / 1000.0, [&] { return h->done >= mine; })) {
         o.rc = h->rc; o.detail = h->detail;
         return o;
     }
@@ -151,7 +165,10 @@ inline void watch_loop() {
     for (;;) {
         if (!w.armed) { w.cv.wait(lk); continue; }
         const double left = w.begun + w.bound_s - now_s();
-        if (left > 0) { w.cv.wait_for(lk, std::chrono::duration<double>(left < 0.25 ? left : 0.25)); continue; }
+        if (left > 0) {  // (woken early by every begin / end; a slice of at most 250 ms otherwise)
+            w.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(std::chrono::duration<double>(left < 0.25 ? left : 0.25)));
+            continue;
+        }
         // the phase has outlived its bound: say so and end the process (no unwinding: whatever is stuck would be waited for again)
         char head[512];
         snprintf(head, sizeof head, "gpuart watchdog (pid %d): phase '%s' has been running for %.1f s (bound %.1f s) — giving up.\n"
