@@ -601,12 +601,27 @@ GD_FN void trav_enter(Trav &t, uint32_t ref, float entry) {
     }
 }
 
+#ifdef GD_STEP_STATS
+__device__ unsigned long long g_pop_stats[4];  // [0] trips of trav_pop's loop as waves execute them, [1] lanes in those trips, [2] calls (wave level), [3] lanes in the calls
+#endif
 /// Returns to the nearest pending upper child that is still worth visiting (or finishes).
 /// `band`: 1 in the reference's order; GD_NEAREST_BAND in an ordered NEAREST walk.
 template <bool COUNT>
 GD_FN void trav_pop(Trav &t, TravStack &st, WorkCounters *wc, bool writer = true, float band = 1.0f) {
     const float limit = t.closest * band;  // (x 1.0f is exact)
+#ifdef GD_STEP_STATS
+    {
+        const unsigned long long act = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) { atomicAdd(&g_pop_stats[2], 1ull); atomicAdd(&g_pop_stats[3], (unsigned long long)__popcll(act)); }
+    }
+#endif
     for (;;) {
+#ifdef GD_STEP_STATS
+        {   // diagnostic build: trips of this loop as the WAVE executes them (one count per trip with any lane in it) and lane-level pops
+            const unsigned long long act = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) { atomicAdd(&g_pop_stats[0], 1ull); atomicAdd(&g_pop_stats[1], (unsigned long long)__popcll(act)); }
+        }
+#endif
         if (st.sp == 0) { t.state = TRAV_DONE; return; }
         StackEntry e = st.pop(writer);
         if (e.pe > limit) continue;       // the reference's parent re-test fails: skip the upper child

@@ -19,7 +19,7 @@ L.gpuart_hip_debug_step_stats.argtypes = [C.c_void_p, C.c_void_p]
 
 
 def stats(r):
-    ev = np.zeros(8, np.uint64)
+    ev = np.zeros(12, np.uint64)
     assert L.gpuart_hip_debug_step_stats(r.backend.ctx, ev.ctypes.data_as(C.c_void_p)) == 0
     return [int(v) for v in ev]
 
@@ -36,9 +36,13 @@ for w in WORK:
     for _ in range(K):
         r.path_tracing_pass()
     r.finish()
-    box, box_lanes, leaf, leaf_lanes, rounds, held, refills = stats(r)[:7]
+    st = stats(r)
+    box, box_lanes, leaf, leaf_lanes, rounds, held, refills = st[:7]
+    trips, trip_lanes, calls, call_lanes = st[8:12]
     print("%s, %d passes through k_trace:" % (w, K))
     print("  box steps  %12d   lanes per box step  %5.1f of 64" % (box, box_lanes / max(1, box)))
     print("  leaf steps %12d   lanes per leaf step %5.1f of 64   (one leaf step per %.2f box steps)" % (leaf, leaf_lanes / max(1, leaf), box / max(1, leaf)))
     print("  rounds     %12d   lanes holding a ray %5.1f of 64   refill episodes %d (one per %.1f rounds)" % (rounds, held / max(1, rounds), refills, rounds / max(1, refills)))
+    print("  pops (trav_pop, all kernels of the run): %d wave-level calls with %.1f lanes each; the loop runs %.2f trips per call, %.1f lanes per trip" % (
+        calls, call_lanes / max(1, calls), trips / max(1, calls), trip_lanes / max(1, trips)))
     r.close()
