@@ -1724,8 +1724,10 @@ int gpuart_hip_debug_step_stats(gpuart_hip_ctx *c, unsigned long long *out) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_stats), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_step_stats), zero, sizeof(zero)));
-    HIP_TRY(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(gd::g_pop_stats), 4 * sizeof(unsigned long long)));   // out: 12 words
+    HIP_TRY(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(gd::g_pop_stats), 4 * sizeof(unsigned long long)));   // out: 16 words
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gd::g_pop_stats), zero, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out + 12, HIP_SYMBOL(g_phase_ticks), 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), zero, 4 * sizeof(unsigned long long)));
     return 0;
 }
 #endif

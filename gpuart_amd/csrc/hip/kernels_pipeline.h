@@ -33,6 +33,7 @@ namespace {
 
 #ifdef GD_STEP_STATS
 __device__ unsigned long long g_step_stats[8];
+__device__ unsigned long long g_phase_ticks[4];  // k_trace: summed over waves, shader-clock ticks in refill / traverse / settle + retire
 #endif
 
 /// Per-path state of one run of the wavefront pipeline: `batch` passes x `n_slots` pixel slots (pixel slot p: 8x8 tile
@@ -343,6 +344,10 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
     // diagnostic build (never the product): how full the wave's steps are — box steps and the lanes in them, leaf steps and the lanes in
     // them, rounds of the wide loop and the lanes that hold a ray in them, refill episodes (tools/step_stats.py)
     uint32_t ss_box = 0, ss_box_lanes = 0, ss_leaf = 0, ss_leaf_lanes = 0, ss_rounds = 0, ss_held = 0, ss_refills = 0;
+    unsigned long long ss_t_refill = 0, ss_t_trav = 0, ss_t_retire = 0, ss_mark = __builtin_amdgcn_s_memtime();  // shader-clock ticks per phase of the outer loop
+#define GD_SS_PHASE(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ss_mark; ss_mark = now_; }
+#else
+#define GD_SS_PHASE(acc)
 #endif
     for (;;) {
         // ---- refill idle lanes from the queue
@@ -381,6 +386,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             if (take == want) break;
         }
         const unsigned long long flying = __ballot(slot != SLOT_INVALID && sub == 0);
+        GD_SS_PHASE(ss_t_refill)
         if (flying == 0) {
             if (exhausted) break;
             continue;
@@ -455,6 +461,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             // a draining wave may move to pairs / quads once it is down to 32 rays
             if (THIN_OK && exhausted && (uint32_t)__popcll(busy) <= BLOCK / 2) break;
         }
+        GD_SS_PHASE(ss_t_trav)
         // ---- a finished nearest-first query that cannot vouch for its answer walks again, in the reference's order (every replica alike)
         if (NEAR && slot != SLOT_INVALID && t.state == TRAV_DONE && trav_settle<NEAR>(t, !shadow && !refwalk)) {
             refwalk = true;
@@ -473,12 +480,14 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
             }
         }
         if (slot != SLOT_INVALID && t.state == TRAV_DONE) slot = SLOT_INVALID;
+        GD_SS_PHASE(ss_t_retire)
     }
     if (COUNT) flush_counters(wc, 0, gcounters);
 #ifdef GD_STEP_STATS
     if (lane_id() == 0) {
         const uint32_t v[7] = {ss_box, ss_box_lanes, ss_leaf, ss_leaf_lanes, ss_rounds, ss_held, ss_refills};
         for (int k = 0; k < 7; k++) atomicAdd(&g_step_stats[k], (unsigned long long)v[k]);
+        atomicAdd(&g_phase_ticks[0], ss_t_refill); atomicAdd(&g_phase_ticks[1], ss_t_trav); atomicAdd(&g_phase_ticks[2], ss_t_retire);
     }
 #endif
 }

@@ -19,7 +19,7 @@ L.gpuart_hip_debug_step_stats.argtypes = [C.c_void_p, C.c_void_p]
 
 
 def stats(r):
-    ev = np.zeros(12, np.uint64)
+    ev = np.zeros(16, np.uint64)
     assert L.gpuart_hip_debug_step_stats(r.backend.ctx, ev.ctypes.data_as(C.c_void_p)) == 0
     return [int(v) for v in ev]
 
@@ -39,10 +39,14 @@ for w in WORK:
     st = stats(r)
     box, box_lanes, leaf, leaf_lanes, rounds, held, refills = st[:7]
     trips, trip_lanes, calls, call_lanes = st[8:12]
+    t_refill, t_trav, t_retire = st[12:15]
     print("%s, %d passes through k_trace:" % (w, K))
     print("  box steps  %12d   lanes per box step  %5.1f of 64" % (box, box_lanes / max(1, box)))
     print("  leaf steps %12d   lanes per leaf step %5.1f of 64   (one leaf step per %.2f box steps)" % (leaf, leaf_lanes / max(1, leaf), box / max(1, leaf)))
     print("  rounds     %12d   lanes holding a ray %5.1f of 64   refill episodes %d (one per %.1f rounds)" % (rounds, held / max(1, rounds), refills, rounds / max(1, refills)))
     print("  pops (trav_pop, all kernels of the run): %d wave-level calls with %.1f lanes each; the loop runs %.2f trips per call, %.1f lanes per trip" % (
         calls, call_lanes / max(1, calls), trips / max(1, calls), trip_lanes / max(1, trips)))
+    tt = max(1, t_refill + t_trav + t_retire)
+    print("  wave time by phase of k_trace's outer loop: refill %.1f %%, traverse %.1f %%, settle + retire %.1f %%   (refill episode: %.0f ticks; a round of the traverse loop: %.0f ticks of the 100 MHz clock)" % (
+        100.0 * t_refill / tt, 100.0 * t_trav / tt, 100.0 * t_retire / tt, t_refill / max(1, refills), t_trav / max(1, rounds)))
     r.close()
