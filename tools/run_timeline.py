@@ -19,6 +19,11 @@ r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
 r.set_primitives(B.make_prims(S.scene_d()))
 r.set_max_path_segments(8)
 r.backend.set_mode(5)
+SHARE = int(os.environ.get("TL_SHARE", "1"))  # TL_SHARE=8: rank 0's share of the frame among 8 ranks (what an N = 8 rank runs)
+if SHARE > 1:
+    from gpuart_amd import sharding
+    y0, rows, band, stride, _ = sharding.interleaved_rows(0, SHARE, H)
+    assert r.set_interleaved_tile(0, y0, W, rows, band, stride)
 L = B.hip_lib()
 L.gpuart_hip_debug_run_hist.argtypes = [C.c_void_p, C.c_void_p]
 hist = np.zeros(256, np.uint64)
