@@ -25,6 +25,10 @@ if WORKLOAD in ("cluster", "tree"):  # the reference's primitive-list scenes on 
 r.set_primitives(B.make_prims(S.scene_d(660, 660) if WORKLOAD == "dragon871k" else S.scene_p() if WORKLOAD == "cfg2" else
                               S.cluster_scene() if WORKLOAD == "cluster" else S.tree_scene() if WORKLOAD == "tree" else S.scene_d()))
 r.set_max_path_segments(4 if WORKLOAD == "cfg2" else 5 if WORKLOAD in ("cluster", "tree") else 8)
+if int(os.environ.get("SHARE", "1")) > 1:  # SHARE=N: rank 0's share of the frame among N ranks (interleaved 8-row bands, as bench.py --gpus N)
+    from gpuart_amd import sharding
+    y0, rows, band, stride, _ = sharding.interleaved_rows(0, int(os.environ["SHARE"]), H)
+    assert r.set_interleaved_tile(0, y0, W, rows, band, stride)
 r.backend.set_mode(int(os.environ.get('GPUART_MODE', '0')))
 r.backend.set_timing(int(os.environ.get('GPUART_TIMING', '0')))
 for _ in range(REPS):
