@@ -420,7 +420,9 @@ __global__ void __launch_bounds__(64) k_step(const float4 *__restrict__ recs, ui
 //      them out with 12 selects. A child that is STACKED needs its own six parameters again when it is popped: POP_PCT per cent of the
 //      lanes (data-dependent, divergent) first fetch a 32-byte box of their own from a second array and recompute the six parameters,
 //      as a pop would. MODE 0: fetch + decode + two quick box tests; 1: fetch only.
-template <int MODE, int POP_PCT>
+//      SAME: the node's own box sits in the second half of its own 64-byte record instead (same line, same working set as the shipped layout):
+//      a lane that descends fetches the first 32 bytes, a lane that popped all 64.
+template <int MODE, int POP_PCT, bool SAME = false>
 __global__ void __launch_bounds__(64) k_step32(const float4 *__restrict__ recs, const float4 *__restrict__ boxes, uint32_t mask, int iters, float *out, unsigned long long *cycles) {
     using namespace gd;
     uint32_t idx = (blockIdx.x * 64 + threadIdx.x) * 2654435761u;
@@ -435,18 +437,22 @@ __global__ void __launch_bounds__(64) k_step32(const float4 *__restrict__ recs, 
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
         uint32_t h = 0;
-        if (POP_PCT > 0 && ((idx >> 9) % 100u) < (uint32_t)POP_PCT) {  // this lane's node came off the stack: its own box, fetched; six parameters
-            const float4 *b = boxes + 2 * (size_t)((idx >> 3) & mask);
-            float4 lo = b[0], hi = b[1];
+        const bool popped = POP_PCT > 0 && ((idx >> 9) % 100u) < (uint32_t)POP_PCT;  // this lane's node came off the stack: its own box, fetched; six parameters
+        const float4 *p = recs + (SAME ? 4 : 2) * (size_t)(idx & mask);
+        float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+        if (popped) {  // (the requests first, all of them; the arithmetic on the own box after the record's requests are out)
+            const float4 *bx = SAME ? p + 2 : boxes + 2 * (size_t)((idx >> 3) & mask);
+            lo = bx[0]; hi = bx[1];
+        }
+        float4 a = p[0], b = p[1];
+        asm volatile("" : "+v"(a.w), "+v"(b.w));
+        if (popped) {
             asm volatile("" : "+v"(lo.w), "+v"(hi.w));
             kp[0] = (lo.x * 1e-9f - r.o.x) * rdiv.x; kp[1] = (hi.x * 1e-9f + 1 - r.o.x) * rdiv.x;
             kp[2] = (lo.y * 1e-9f - r.o.y) * rdiv.y; kp[3] = (hi.y * 1e-9f + 1 - r.o.y) * rdiv.y;
             kp[4] = (lo.z * 1e-9f - r.o.z) * rdiv.z; kp[5] = (hi.z * 1e-9f + 1 - r.o.z) * rdiv.z;
             h += __float_as_uint(lo.w) + __float_as_uint(hi.w);
         }
-        const float4 *p = recs + 2 * (size_t)(idx & mask);
-        float4 a = p[0], b = p[1];
-        asm volatile("" : "+v"(a.w), "+v"(b.w));
         const uint32_t ra = __float_as_uint(a.w), rb = __float_as_uint(b.w);
         h += ra + rb;
         if (MODE == 0) {
@@ -663,6 +669,10 @@ int main(int argc, char **argv) {
                 timed(nm("step_fetch32B_implicit_and_2_quick_box_tests_pop0"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 0><<<n, 64>>>(recs, boxes2, 2 * m + 1, 1024, o, c); });
                 timed(nm("step_fetch32B_implicit_and_2_quick_box_tests_pop25"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 25><<<n, 64>>>(recs, boxes2, 2 * m + 1, 1024, o, c); });
                 timed(nm("step_fetch32B_implicit_and_2_quick_box_tests_pop50"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 50><<<n, 64>>>(recs, boxes2, 2 * m + 1, 1024, o, c); });
+                // the same with the popped node's own box in the second half of its own 64-byte record (no second array, the shipped working set)
+                timed(nm("step_fetch32of64B_implicit_and_2_quick_box_tests_pop0"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 0, true><<<n, 64>>>(recs, recs, m, 1024, o, c); });
+                timed(nm("step_fetch32of64B_implicit_and_2_quick_box_tests_pop25_same_line"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 25, true><<<n, 64>>>(recs, recs, m, 1024, o, c); });
+                timed(nm("step_fetch32of64B_implicit_and_2_quick_box_tests_pop40_same_line"), w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step32<0, 40, true><<<n, 64>>>(recs, recs, m, 1024, o, c); });
                 timed("step_2_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2><<<n, 64>>>(recs, m, 1024, o, c); });
                 timed("step_2_quick_box_tests_only", w, 1024.0, "wave-steps", [&](int n, float *o, unsigned long long *c) { k_step<2, true><<<n, 64>>>(recs, m, 1024, o, c); });
             }
