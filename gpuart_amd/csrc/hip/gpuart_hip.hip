@@ -37,6 +37,10 @@ thread_local std::string g_last_error;
 // hardware queues (default 4) and kernels of streams that share a queue serialise, which would undo the overlap
 // the pass lanes exist for; ask for more queues unless the user has chosen a value. Must happen before the HIP
 // runtime initialises, hence a load-time constructor (bench.py also sets it before importing torch).
+// Measured in round 5 (rocprofv3 kernel traces, profiles/r05/planner_even_runs.txt): whatever the value, a process gets EIGHT hardware
+// queues on this platform — the primary stream's and seven more —, so the eighth pass lane shares a queue (with the primary stream,
+// whose k_accumulate launches wait for runs in pass order: a run queued behind such a wait starts late). The planner therefore cuts
+// planned sequences so that the eighth lane is only used when all eight have work (run_planner.h plan(), on_flush()).
 __attribute__((constructor)) void request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
 
 int fail(int code, const std::string &msg) {
@@ -175,6 +179,7 @@ int drain(gpuart_hip_ctx *c) {
         if (l.main) HIP_TRY(hipStreamSynchronize(l.main));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->next_lane = 0;  // every lane is idle: the next sequence starts on the first one again (a plan of seven runs stays off the eighth lane, see above)
     return 0;
 }
 
@@ -450,10 +455,10 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->plan.lanes_total = (uint32_t)c->lanes.size();
     c->plan.batch_limit = env_u32("GPUART_HIP_MAX_BATCH", MAX_BATCH, 1, MAX_BATCH);
     c->plan.batch_paths = (size_t)env_u32("GPUART_HIP_BATCH_MPATHS", 16, 1, 256) << 20;
-    c->plan.plan_run_factor = env_u32("GPUART_HIP_PLAN_RUN_PERCENT", 75, 1, 1000) / 100.0;
+    c->plan.plan_run_factor = env_u32("GPUART_HIP_PLAN_RUN_PERCENT", 0, 0, 1000) / 100.0;  // 0: as many equal runs as lanes (run_planner.h)
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->plan.min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
-    c->plan.lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 16384, 64, 262144) << 20;
+    c->plan.lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 32768, 64, 262144) << 20;
     c->plan.small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 6400, 0, 1 << 20) << 10;
     c->gather_timeout_ms = env_u32("GPUART_HIP_GATHER_TIMEOUT_MS", 60000, 0, 3600000);
     for (auto &l : c->lanes) {

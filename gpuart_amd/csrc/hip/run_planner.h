@@ -21,8 +21,8 @@ struct RunPlanner {
     size_t batch_paths = (size_t)16 << 20;     ///< passes are batched while one run stays within this many paths
     size_t min_run_paths = (size_t)2 << 20;    ///< a pipeline run is not made smaller than this many paths
     size_t small_paths = (size_t)6400 << 10;   ///< mode 0: a planned sequence of at most this many paths is ONE k_run launch (0: never)
-    size_t lane_budget = (size_t)16 << 30;     ///< bytes of wavefront path state over all lanes
-    double plan_run_factor = 0.75;             ///< run length = this x sqrt(planned work), in units of 2M paths
+    size_t lane_budget = (size_t)32 << 30;     ///< bytes of wavefront path state over all lanes (8 lanes of 8 passes at 1080p: 17.6 GB)
+    double plan_run_factor = 0;                ///< 0: as many equal runs as lanes (plan()); > 0: the rule of rounds 2-4, run length = this x sqrt(planned work) in units of 2M paths
 
     // ---- state ---------------------------------------------------------------------------------------------------------
     uint32_t n_slots = 0;         ///< path slots of the tile (8x8-tile padded)
@@ -72,11 +72,15 @@ struct RunPlanner {
         return passes <= 1 || passes * (size_t)n_slots <= small_paths;  // one pass observed alone: k_run at every frame size
     }
 
-    /// Passes per pipeline run. Runs should be long (a persistent launch that takes many rays per lane wastes less of its
-    /// instructions on draining its last rays) and numerous (their kernels fill each other's tails, and more runs than lanes
-    /// keeps the lanes out of step). For a planned sequence of u units of work (1 unit = 2M paths, one 1080p pass) the best
-    /// run length measured on cfg3 was 1, 1, 2-3, 3-4, 6 units for u = 2, 4, 8, 20, 64 — about 0.75 sqrt(u); never below
-    /// `min_run_paths`, never above max_batch. Without a plan: 8M paths.
+    /// Passes per pipeline run of a planned sequence of K passes: AS MANY EQUAL RUNS AS THERE ARE LANES — ceil(K / lanes) passes each;
+    /// a sequence longer than the lanes hold at once (lanes x max_batch) in 2, 3, ... rounds of that many runs. Measured on cfg3, K = 8 ... 48
+    /// x every run length 1 ... 9 (profiles/r05/run_length_sweep.txt) and K = 64, 72, 128 (planner_lanes_rule.txt): with 8 lanes the best
+    /// length is the smallest one that needs no more than 8 runs; one or two runs MORE than a multiple of the lanes is the worst a plan can
+    /// do (+8 ... 15 %: the stragglers start when a lane frees up and finish with nothing to overlap with — 24 passes as 8 x 3 on the 7
+    /// lanes a 16 GB budget gave: 0.95 ms per pass, on 8 lanes 0.81; 72 as 9 x 8: 0.87, as 15 x 5: 0.785), and longer runs than that rule
+    /// gives pack lanes no better. Rounds 2-4 used 0.75 sqrt(work) (plan_run_factor > 0 brings it back): fitted to K = 2, 4, 8, 20, 64,
+    /// right there, and in resonance with the lane count at K = 22-24, 29-32. Never below `min_run_paths` (a share's small passes),
+    /// never above max_batch. Without a plan: 8M paths.
     void plan() {
         if (!n_slots) { run_passes = 1; return; }
         const double unit = (double)((size_t)2 << 20);
@@ -85,13 +89,23 @@ struct RunPlanner {
         if (planned_passes && (mode == 0 || mode == 5) && planned_passes <= max_batch &&
             (small_paths ? planned_passes == 1 || (size_t)planned_passes * n_slots <= small_paths : mode == 5)) {
             want = planned_passes;  // a small sequence is ONE run of the persistent kernel (uses_run_kernel)
-        } else if (planned_passes) {
+        } else if (planned_passes && plan_run_factor > 0) {
             const double u = (double)planned_passes * n_slots / unit;
             want = (size_t)(plan_run_factor * std::sqrt(u) * unit / n_slots);
+        } else if (planned_passes) {
+            const size_t lanes = std::max<size_t>(1, lanes_in_use);
+            const size_t rounds = (planned_passes + lanes * max_batch - 1) / (lanes * max_batch);
+            want = (planned_passes + rounds * lanes - 1) / (rounds * lanes);
         } else {
             want = std::max<size_t>(1, ((size_t)8 << 20) / n_slots);
         }
         run_passes = std::min<size_t>(max_batch, std::max(min_run, want));
+        // ... of EQUAL length: 20 passes in runs of 6 end in a run of 2 that has nothing left to overlap with (four runs of 5 took 5 % less
+        // on a quarter-frame share, where min_run_paths sets the length)
+        if (planned_passes > run_passes) {
+            const size_t n_runs = (planned_passes + run_passes - 1) / run_passes;
+            run_passes = std::min<size_t>(max_batch, std::max(min_run, (planned_passes + n_runs - 1) / n_runs));
+        }
     }
 
     /// One more pass was collected. Returns how many pending passes start NOW as one run (0: keep collecting).
@@ -110,6 +124,9 @@ struct RunPlanner {
         std::vector<size_t> runs;
         if (!pending) return runs;
         size_t n = uses_run_kernel(pending) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)lanes_in_use, pending, pending * n_slots / std::max<size_t>(1, min_run_paths)}));
+        // the remainder of a PLANNED sequence is the plan's last, shorter run: cut up it would take lanes the plan left alone (20 passes =
+        // 6 x 3 + 2: a seventh run, not a seventh and an eighth — the eighth lane shares its hardware queue, see gpuart_hip.hip)
+        if (planned_passes && !plan_run_factor && pending <= run_passes) n = 1;
         n = std::max(n, (pending + max_batch - 1) / max_batch);
         for (size_t k = 0, first = 0; k < n; k++) {
             const size_t count = (pending - first) / (n - k);

@@ -86,6 +86,27 @@ def test_planner_defaults_match_the_design_notes():
     assert max(x[3] for x in r) <= r[0][2] < 8 and sum(x[3] for x in r) == 20
 
 
+def test_a_planned_sequence_is_cut_into_as_many_equal_runs_as_there_are_lanes():
+    """run_planner.h plan(), the rule of round 5 (plan_percent = 0, the library's default; lane budget 32 GB -> 8 lanes at 1080p):
+    ceil(K / 8) passes per run; beyond 64 passes (8 lanes x 8 passes) in rounds of 8 runs; a share's small passes stay at >= 2M paths."""
+    new = dict(plan_percent=0, lane_budget_mb=32768)
+    def lengths(K, frame=(1920, 1080), share=None):
+        ops = [(RESIZE,) + frame] + ([(SHARE, 0, share)] if share else []) + [(MODE, 3, 0), (PLAN, K, 0), (PASS, K, 0), (FLUSH, 0, 0)]
+        runs = plan(ops, **new)
+        check(ops, runs, new)
+        return [r[3] for r in runs]
+    assert lengths(20) == [3, 3, 3, 3, 3, 3, 2]
+    assert lengths(24) == [3] * 8 and lengths(32) == [4] * 8 and lengths(64) == [8] * 8
+    assert lengths(25) == [4] * 6 + [1] and lengths(9) == [2, 2, 2, 2, 1]
+    assert lengths(72) == [5] * 14 + [2] and lengths(128) == [8] * 16    # two rounds of 8 runs, never 9 runs of 8
+    assert lengths(20, share=4) == [4] * 5                                  # 0.52M paths per pass: not below 2M paths (4 passes) a run
+    # the rule of rounds 2-4 is still there for A/B (GPUART_HIP_PLAN_RUN_PERCENT=75)
+    ops = [(RESIZE, 1920, 1080), (MODE, 3, 0), (PLAN, 24, 0), (PASS, 24, 0), (FLUSH, 0, 0)]
+    assert [r[3] for r in plan(ops, plan_percent=75, lane_budget_mb=32768)] == [3] * 8
+    old = [r[3] for r in plan([(RESIZE, 1920, 1080), (MODE, 3, 0), (PLAN, 64, 0), (PASS, 64, 0), (FLUSH, 0, 0)], plan_percent=75)]
+    assert old[:10] == [6] * 10 and sum(old) == 64
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_sequences_never_overrun_a_lane(seed):
     rng = np.random.RandomState(1000 + seed)
@@ -96,7 +117,7 @@ def test_random_sequences_never_overrun_a_lane(seed):
             cfg = dict(batch_limit=int(rng.choice([1, 2, 5, 8, 64])), lanes=int(rng.choice([1, 2, 3, 8, 32])),
                        batch_mpaths=int(rng.choice([1, 4, 16, 64])), min_run_kpaths=int(rng.choice([64, 512, 2048, 8192])),
                        small_kpaths=int(rng.choice([0xffffffff, 64, 6400, 100000])), lane_budget_mb=int(rng.choice([64, 1024, 16384])),
-                       plan_percent=int(rng.choice([10, 75, 300])))
+                       plan_percent=int(rng.choice([0, 0, 10, 75, 300])))
         W, H = frames[rng.randint(len(frames))]
         ops = [(RESIZE, W, H)]
         for _ in range(rng.randint(5, 60)):
