@@ -11,7 +11,7 @@ from gpuart_amd import synth_scenes as S  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-W, H = 1920, 1080
+W, H = [int(x) for x in os.environ.get("FRAME", "1920x1080").split("x")]  # FRAME=3840x2160
 cam = dict(S.BENCH_CAMERA); cam["dir"] = S.camera_dir(cam)
 r = B.Renderer(W, H, cam)
 r.set_user_sphere(S.USER_SPHERE[:3], 0.0, 0.0)
