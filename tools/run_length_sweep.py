@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ms per pass of cfg3 for K passes cut into runs of exactly L passes (+ a remainder run), K and L swept: the data behind run_planner.h's
-run length.   GPUART_LIBDIR=gpuart_amd/lib_ab/uneven python3 tools/run_length_sweep.py K0 K1 [L0 L1]   (a library built with
--DGPUART_PLAN_UNEVEN=1: the run length is then min(MAX_BATCH, 4 x the rule) = MAX_BATCH)"""
+run length (profiles/r05/run_length_sweep.txt was taken on the library of the commit before the planner change, whose runs were exactly
+MAX_BATCH passes + a remainder; today's planner evens the runs out: K = 20, L = 6 becomes 4 x 5).   python3 tools/run_length_sweep.py K0 K1 [L0 L1]"""
 import os
 import re
 import subprocess
