@@ -37,10 +37,10 @@ thread_local std::string g_last_error;
 // hardware queues (default 4) and kernels of streams that share a queue serialise, which would undo the overlap
 // the pass lanes exist for; ask for more queues unless the user has chosen a value. Must happen before the HIP
 // runtime initialises, hence a load-time constructor (bench.py also sets it before importing torch).
-// Measured in round 5 (rocprofv3 kernel traces, profiles/r05/planner_even_runs.txt): whatever the value, a process gets EIGHT hardware
-// queues on this platform — the primary stream's and seven more —, so the eighth pass lane shares a queue (with the primary stream,
-// whose k_accumulate launches wait for runs in pass order: a run queued behind such a wait starts late). The planner therefore cuts
-// planned sequences so that the eighth lane is only used when all eight have work (run_planner.h plan(), on_flush()).
+// Measured in round 5 (rocprofv3 kernel traces, profiles/r05/planner_even_runs.txt): whatever the value, the streams of a process share
+// EIGHT hardware queues on this platform — the primary stream's and seven more, so the eighth pass lane shares one (a stream created
+// with a priority gets a queue of its own: tried for the primary stream, nine queues, same times). Sharing by itself costs nothing
+// measurable; sequences of seven runs that rotated over eight lanes were 1-3 % slower than on seven, so drain() restarts the rotation.
 __attribute__((constructor)) void request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
 
 int fail(int code, const std::string &msg) {

@@ -125,7 +125,7 @@ struct RunPlanner {
         if (!pending) return runs;
         size_t n = uses_run_kernel(pending) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)lanes_in_use, pending, pending * n_slots / std::max<size_t>(1, min_run_paths)}));
         // the remainder of a PLANNED sequence is the plan's last, shorter run: cut up it would take lanes the plan left alone (20 passes =
-        // 6 x 3 + 2: a seventh run, not a seventh and an eighth — the eighth lane shares its hardware queue, see gpuart_hip.hip)
+        // 6 x 3 + 2: a seventh run, not a seventh and an eighth)
         if (planned_passes && !plan_run_factor && pending <= run_passes) n = 1;
         n = std::max(n, (pending + max_batch - 1) / max_batch);
         for (size_t k = 0, first = 0; k < n; k++) {
