@@ -339,7 +339,9 @@ def main():
             arrivals.put("gpuart_arrived_%s_%d" % (tag, rank))
         if gather_note is None:
             try:
-                with phase("frame gather #%s (gpuart_hip_gather + gpuart_hip_wait)" % tag, int(args.gather_timeout * 1000) + phase_ms):
+                # (the phase's bound sits ABOVE the library's own: its ERR_TIMEOUT comes first and names the missing ranks; the watchdog's
+                #  exit is for what that does not cover — GPUART_BENCH_PHASE_TIMEOUT_S=0 must not make the two race)
+                with phase("frame gather #%s (gpuart_hip_gather + gpuart_hip_wait)" % tag, int(args.gather_timeout * 1000) + max(phase_ms, 10000)):
                     be.gather(1, divide_by, 0, full.data_ptr() if rank == 0 else 0)
                     be.wait(int(args.gather_timeout * 1000))
             except B.HipError as e:
@@ -392,6 +394,7 @@ def main():
     be.kernel_time(0, reset=True)
     be.kernel_time(1, reset=True)
     reps = []  # per repetition: (max over ranks of the wall time, this rank's render time, this rank's gather time)
+    phase_lines = B.phase_log(False)  # the timed gathers keep their watchdog and lose their two stderr lines (a rank's job is ~3 ms at N = 8)
     for _ in range(max(1, args.repeats)):
         r.set_seed(5489)
         if dist is not None:
@@ -415,6 +418,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax[0])
         reps.append((dt, t_render, t_gather))
+    B.phase_log(phase_lines)
     pass_ms, passes = be.kernel_time(0, reset=True)
     kernel_ms, launches = be.kernel_time(1, reset=True)
     be.set_timing(1)

@@ -106,6 +106,35 @@ RATIO_QUANTITIES = {
 }
 
 
+def finish_roofline(roof, bytes_per_launch, trace, dominant):
+    """What a reader should take away, added once every block is filled in:
+      * `binding`: the resource the pass comes CLOSEST to saturating — the largest of the like-by-like fractions of lane slots, vector-L1
+        accesses, node visits and the aggregate L2 rate — with that fraction: the contract's top-level `frac` prices a cache-resident tree
+        against HBM, which is not what limits it;
+      * `per_launch_frac_range`: the contract's per-launch fraction under the two schedules this invocation observed — the timed passes (HIP
+        events, live) and the un-instrumented rocprofv3 --kernel-trace child: the same bytes per launch over two average launch durations.
+        How far they lie apart is how much the figure depends on how many launches of other pass lanes overlap a launch, i.e. how little it
+        says about the kernel itself."""
+    cands = {"lane_slots": roof["lane_slots"].get("frac"), "l1_accesses": roof["l1_accesses"].get("frac"), "node_visits": roof["node_visits"].get("frac"),
+             "l2_rate": roof["hbm"].get("algorithmic_rate_over_l2_peak")}
+    have = {k: v for k, v in cands.items() if v is not None}
+    if have:
+        top = max(have, key=lambda k: have[k])
+        roof["binding"] = {"resource": top, "frac": have[top], "candidates": cands,
+                           "quantity": RATIO_QUANTITIES.get(top, "algorithmic bytes per second of wall time against the guide's aggregate L2 rate"),
+                           "note": "the largest of the fractions that divide like by like (each block says how it is measured); none is near 1: the "
+                                   "dominant kernel is bound by dependent latency (its waves' s_waitcnt share: %s_wave_states), not by a throughput" % dominant}
+    fr = {"timed_passes_hip_events": roof.get("frac"), "rocprof_trace_child": None}
+    if bytes_per_launch and trace and dominant in trace and trace[dominant][0]:
+        avg_ms = trace[dominant][1] / trace[dominant][0]
+        fr["rocprof_trace_child"] = _r(bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        fr["rocprof_trace_avg_ms"] = _r(avg_ms, 5)
+    vals = [v for v in (fr["timed_passes_hip_events"], fr["rocprof_trace_child"]) if v is not None]
+    roof["per_launch_frac_range"] = {"min": min(vals) if vals else None, "max": max(vals) if vals else None, **fr,
+                                     "note": "the contract's frac (algorithmic bytes of one launch / average launch duration / 8 TB/s) under the two schedules "
+                                             "observed; a launch's duration depends on how many launches of other pass lanes run beside it (kernel_concurrency)"}
+
+
 def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, reference, kernel_events, dominant="k_trace", passes_timed=None):
     """The `roofline` object of the bench line.
       ms_per_step      : wall time of one timed pass (median repetition), ms
@@ -179,6 +208,7 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
                             "memory is `traffic_*` (PMC)"},
             "kernels": None}
     if not prof:
+        finish_roofline(roof, bytes_per_launch, trace, dominant)
         return roof
     valu_t, valu_f = prof.get("valu", ({}, {}))
     wave_t, wave_f = prof.get("wave", ({}, {}))
@@ -254,6 +284,7 @@ def assemble_roofline(ms_per_step, passes_profiled, prof, trace, executed, refer
         rows.append(row)
     rows.sort(key=lambda r: -(r.get("ms_summed_per_pass") or 0.0))
     roof["kernels"] = rows
+    finish_roofline(roof, bytes_per_launch, trace, dominant)
     dom = next((r for r in rows if r["kernel"] == dominant), None)
     roof[dominant + "_wave_states"] = dom.get("wave_states") if dom else None
     roof["kernels_note"] = ("per kernel family and pass: ms_summed = kernel durations of an un-instrumented --kernel-trace child (launches overlap: the "

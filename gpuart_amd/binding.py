@@ -248,6 +248,11 @@ def phase_end():
     hip_lib().gpuart_hip_phase_end()
 
 
+def phase_log(on):
+    """gpuart_hip_phase_log: phase lines on / off from now on (the watchdog stays armed either way); returns the previous setting."""
+    return bool(hip_lib().gpuart_hip_phase_log(C.c_int(1 if on else 0)))
+
+
 class phase:
     """with phase("communicator init", 120000): ...   (the phase ends when the block does, exception or not)"""
 

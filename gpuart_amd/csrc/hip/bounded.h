@@ -15,6 +15,8 @@
 //     running and the library's most recent error messages of ALL threads, then _exit()s with GPUART_HIP_WATCHDOG_EXIT. For
 //     whatever bounded() does not wrap (a stuck hipMalloc, a driver call, torch.distributed's own rendezvous in bench.py).
 #pragma once
+#include <pthread.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -60,16 +62,47 @@ inline std::string recent_errors() {
     return s;
 }
 
-/// cv.wait_for(lk, timeout, pred) on the STEADY clock, in slices of at most 100 ms of pthread_cond_timedwait (system clock): a wall-clock
-/// jump costs one slice, not the bound — and the sanitizers of this toolchain intercept pthread_cond_timedwait but not the
-/// pthread_cond_clockwait that std::condition_variable::wait_for(steady) compiles to (tools/sanitize_bounded.sh would drown in false reports).
+/// A condition variable whose timed wait runs on CLOCK_MONOTONIC: a wall clock stepped in EITHER direction (NTP, an administrator)
+/// neither shortens nor stretches a bound. pthread_cond_t with pthread_condattr_setclock rather than std::condition_variable:
+/// libstdc++'s wait_until(system_clock) is an absolute CLOCK_REALTIME deadline — a clock stepped backwards blocks for the size of the
+/// step (round 5's version sliced such waits, which bounded a forward step only) — and its wait_for(steady) compiles to
+/// pthread_cond_clockwait, which the sanitizers of this toolchain do not intercept (tools/sanitize_bounded.sh would drown in false
+/// reports); pthread_cond_timedwait they do.
+struct MonoCond {
+    pthread_cond_t c;
+    MonoCond() {
+        pthread_condattr_t a;
+        pthread_condattr_init(&a);
+        pthread_condattr_setclock(&a, CLOCK_MONOTONIC);
+        pthread_cond_init(&c, &a);
+        pthread_condattr_destroy(&a);
+    }
+    ~MonoCond() { pthread_cond_destroy(&c); }
+    MonoCond(const MonoCond &) = delete;
+    MonoCond &operator=(const MonoCond &) = delete;
+    void notify_all() { pthread_cond_broadcast(&c); }
+    void wait(std::unique_lock<std::mutex> &lk) { pthread_cond_wait(&c, lk.mutex()->native_handle()); }
+    template <class Pred> void wait(std::unique_lock<std::mutex> &lk, Pred pred) { while (!pred()) wait(lk); }
+    /// woken or `seconds` of CLOCK_MONOTONIC later, whichever comes first (spurious wake-ups as usual: callers re-check)
+    void wait_for(std::unique_lock<std::mutex> &lk, double seconds) {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double whole = seconds < 0 ? 0 : (seconds > 1e8 ? 1e8 : seconds);
+        ts.tv_sec += (time_t)whole;
+        ts.tv_nsec += (long)((whole - (double)(time_t)whole) * 1e9);
+        if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+        pthread_cond_timedwait(&c, lk.mutex()->native_handle(), &ts);
+    }
+};
+
+/// Waits until pred() holds or `seconds` of the monotonic clock have passed (false).
 template <class Pred>
-inline bool wait_steady(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, double seconds, Pred pred) {
+inline bool wait_steady(MonoCond &cv, std::unique_lock<std::mutex> &lk, double seconds, Pred pred) {
     const double end = now_s() + seconds;
     while (!pred()) {
         const double left = end - now_s();
         if (left <= 0) return false;
-        cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(std::chrono::duration<double>(left < 0.1 ? left : 0.1)));
+        cv.wait_for(lk, left);
     }
     return true;
 }
@@ -94,21 +127,29 @@ inline uint32_t comm_timeout_ms() {
 
 /// Runs `fn` (which returns its rc and may fill a detail string) and waits at most timeout_ms for it. fn must own everything
 /// it touches through captured VALUES or objects that are never freed once the layer is stuck: it may outlive the caller's frame.
-/// One helper thread per process serves the calls (a gather makes two of them inside bench.py's timed region: starting a thread
-/// for each would cost a rank of an 8-GPU run a few per cent of its 3 ms); a helper whose call never returned is abandoned with
-/// it and the next call — the test hook's only: the real entry points refuse once the layer is stuck — gets a fresh one.
+/// One helper thread per CALLING thread serves its calls (a gather makes two of them inside bench.py's timed region: starting a thread
+/// for each would cost a rank of an 8-GPU run a few per cent of its 3 ms). Per calling thread, not per process: a process that drives
+/// its ranks from one thread each (RCCL's other usage model besides one process per GPU) has every rank inside ncclCommInitRank or the
+/// share exchange at the same time, each waiting for the others — round 5's single helper behind one lock let the first rank in and
+/// kept the peers it was waiting for outside (tests/test_gather_inprocess.py, the first time that form ran). RCCL's group state is per
+/// thread, and a calling thread's calls keep their order on its helper. A helper whose call never returned is abandoned with it — the
+/// next call (the test hook's only: the real entry points refuse once the layer is stuck) gets a fresh one —; a helper whose calling
+/// thread ends is told to end.
 struct Helper {
     std::mutex m;
-    std::condition_variable cv_job, cv_done;
+    std::condition_variable cv_job;
+    MonoCond cv_done;
     std::function<int(std::string &)> job;
     unsigned long long posted = 0, done = 0;
+    bool quit = false;
     int rc = 0;
     std::string detail;
 };
 inline void helper_loop(std::shared_ptr<Helper> h) {
     std::unique_lock<std::mutex> lk(h->m);
     for (unsigned long long next = 1;; next++) {
-        h->cv_job.wait(lk, [&] { return h->posted >= next; });
+        h->cv_job.wait(lk, [&] { return h->posted >= next || h->quit; });
+        if (h->posted < next) return;
         std::function<int(std::string &)> fn = std::move(h->job);
         lk.unlock();
         std::string d;
@@ -119,17 +160,24 @@ inline void helper_loop(std::shared_ptr<Helper> h) {
         h->cv_done.notify_all();
     }
 }
+struct HelperOwner {
+    std::shared_ptr<Helper> h;
+    ~HelperOwner() {
+        if (!h) return;
+        std::lock_guard<std::mutex> g(h->m);
+        h->quit = true;
+        h->cv_job.notify_all();
+    }
+};
 inline Outcome bounded(const char *what, uint32_t timeout_ms, std::function<int(std::string &)> fn) {
     Outcome o;
     if (!timeout_ms) { o.rc = fn(o.detail); return o; }
-    static std::mutex callers;                    // one bounded call at a time (they are rare and their order matters to RCCL anyway)
-    static std::shared_ptr<Helper> *helper = new std::shared_ptr<Helper>();
-    std::lock_guard<std::mutex> one(callers);
-    if (!*helper) {
-        *helper = std::make_shared<Helper>();
-        std::thread(helper_loop, *helper).detach();
+    static thread_local HelperOwner own;
+    if (!own.h) {
+        own.h = std::make_shared<Helper>();
+        std::thread(helper_loop, own.h).detach();
     }
-    std::shared_ptr<Helper> h = *helper;
+    std::shared_ptr<Helper> h = own.h;
     std::unique_lock<std::mutex> lk(h->m);
     h->job = std::move(fn);
     const unsigned long long mine = ++h->posted;
@@ -138,10 +186,13 @@ inline Outcome bounded(const char *what, uint32_t timeout_ms, std::function<int(
         o.rc = h->rc; o.detail = h->detail;
         return o;
     }
-    helper->reset();  // that helper stays parked in the call (it keeps its own reference); it is never given another job
+    lk.unlock();
+    own.h.reset();  // that helper stays parked in the call (it keeps its own reference); it is never given another job, nor told to end
     o.timed_out = true;
     o.detail = std::string(what) + " has not returned after " + std::to_string(timeout_ms) + " ms (GPUART_HIP_COMM_TIMEOUT_MS); its thread stays "
                "parked in the call, the communicator layer of this process is out of service";
+    static std::mutex first;  // (several ranks' calls may run out at once: one of them names the layer's state)
+    std::lock_guard<std::mutex> g(first);
     if (!stuck().load()) { stuck_in() = what; stuck().store(true); }
     return o;
 }
@@ -150,12 +201,12 @@ inline Outcome bounded(const char *what, uint32_t timeout_ms, std::function<int(
 #define GPUART_HIP_WATCHDOG_EXIT_CODE 86
 struct Watchdog {
     std::mutex m;
-    std::condition_variable cv;
+    MonoCond cv;
     bool running = false;
     bool armed = false;
     std::string phase;
     double begun = 0, bound_s = 0;
-    bool log = false;
+    bool log = false, log_known = false;
 };
 inline Watchdog &watchdog() { static Watchdog *w = new Watchdog(); return *w; }
 
@@ -165,8 +216,8 @@ inline void watch_loop() {
     for (;;) {
         if (!w.armed) { w.cv.wait(lk); continue; }
         const double left = w.begun + w.bound_s - now_s();
-        if (left > 0) {  // (woken early by every begin / end; a slice of at most 250 ms otherwise)
-            w.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(std::chrono::duration<double>(left < 0.25 ? left : 0.25)));
+        if (left > 0) {  // (woken early by every begin / end)
+            w.cv.wait_for(lk, left);
             continue;
         }
         // the phase has outlived its bound: say so and end the process (no unwinding: whatever is stuck would be waited for again)
@@ -186,8 +237,11 @@ inline int phase_begin(const char *name, uint32_t timeout_ms) {
     std::lock_guard<std::mutex> g(w.m);
     if (!w.running) {
         w.running = true;
-        const char *v = getenv("GPUART_HIP_PHASE_LOG");
-        w.log = !v || atoi(v) != 0;  // default on: a phase line costs nothing and is what a post-mortem needs
+        if (!w.log_known) {
+            const char *v = getenv("GPUART_HIP_PHASE_LOG");
+            w.log = !v || atoi(v) != 0;  // default on: a phase line is what a post-mortem needs
+            w.log_known = true;
+        }
         std::thread(watch_loop).detach();
     }
     w.phase = name ? name : "?";
@@ -197,6 +251,21 @@ inline int phase_begin(const char *name, uint32_t timeout_ms) {
     if (w.log) fprintf(stderr, "gpuart phase begin: %s (pid %d, bound %.1f s)\n", w.phase.c_str(), (int)getpid(), w.bound_s);
     w.cv.notify_all();
     return 0;
+}
+
+/// Phase lines on (1) / off (0) from here on, whatever GPUART_HIP_PHASE_LOG said; returns what it was. For phases inside a timed
+/// region (bench.py's gathers: two fprintf under a lock per gather, where a rank's whole job is ~3 ms): the watchdog stays armed.
+inline int phase_log(int on) {
+    Watchdog &w = watchdog();
+    std::lock_guard<std::mutex> g(w.m);
+    if (!w.log_known) {
+        const char *v = getenv("GPUART_HIP_PHASE_LOG");
+        w.log = !v || atoi(v) != 0;
+        w.log_known = true;
+    }
+    const int was = w.log ? 1 : 0;
+    w.log = on != 0;
+    return was;
 }
 
 inline int phase_end() {

@@ -45,7 +45,8 @@ Rccl *rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         // GPUART_HIP_RCCL_LIBRARY: this file and no other (a site's own build of RCCL; the tests' stand-in whose calls can be made
-        // to never return — tests/stubs/rccl_stub.c — which is how the bounded waits are exercised on one GPU)
+        // to never return and which serves N ranks inside one process — tests/stubs/rccl_stub.cpp — which is how the bounded waits and the
+        // N > 1 transfers are exercised on one GPU)
         if (const char *own = getenv("GPUART_HIP_RCCL_LIBRARY")) {
             r.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
             if (!r.lib) { r.err = std::string("cannot load GPUART_HIP_RCCL_LIBRARY: ") + dlerror(); return; }

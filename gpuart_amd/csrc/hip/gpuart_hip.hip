@@ -636,8 +636,7 @@ int gpuart_hip_render_direct(gpuart_hip_ctx *c, const gpuart_params *p) {
 
 int gpuart_hip_pt_plan(gpuart_hip_ctx *c, uint32_t passes) {
     if (!c) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
-    c->plan.planned_passes = passes;
-    c->plan.plan();
+    c->plan.set_plan(passes);
     return 0;
 }
 
@@ -649,6 +648,7 @@ int gpuart_hip_pt_reset(gpuart_hip_ctx *c) {
     // passes still in flight belong to the accumulation that is being discarded: let them finish first
     int r = drain(c);
     if (r) return r;
+    c->plan.plan_done = 0;  // a new accumulation: the planned sequence, if any, begins again
     HIP_TRY(hipMemsetAsync(c->d_accum, 0, c->plan.tile_pixels * sizeof(float4), c->stream));
     return 0;
 }
@@ -1156,12 +1156,18 @@ int gpuart_hip_comm_init_all(gpuart_hip_ctx *const *ctxs, int n) {
     if (!ctxs || n < 1) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     int r = comm_layer_ok();
     if (r || (r = need_rccl())) return r;
+    // RCCL refuses two ranks of a communicator on one device. An in-process stand-in (GPUART_HIP_RCCL_LIBRARY, tests/stubs/rccl_stub.cpp)
+    // does not: with GPUART_HIP_TEST_SHARED_DEVICE=1 beside it the N > 1 gather runs on a box with one GPU. Test-only, both variables.
+    const char *shared = getenv("GPUART_HIP_TEST_SHARED_DEVICE");
+    const bool one_device_ok = getenv("GPUART_HIP_RCCL_LIBRARY") && shared && shared[0] == '1';
     std::vector<int> devs(n);
     for (int k = 0; k < n; k++) {
         if (!ctxs[k]) return fail(GPUART_HIP_ERR_ARG, "ctx == NULL");
         devs[k] = ctxs[k]->device;
-        for (int m = 0; m < k; m++)
-            if (devs[m] == devs[k]) return fail(GPUART_HIP_ERR_ARG, "two contexts of one communicator on the same device");
+        for (int m = 0; m < k; m++) {
+            if (ctxs[m] == ctxs[k]) return fail(GPUART_HIP_ERR_ARG, "one context given twice");
+            if (devs[m] == devs[k] && !one_device_ok) return fail(GPUART_HIP_ERR_ARG, "two contexts of one communicator on the same device");
+        }
     }
     // a context leaves its previous communicator first (with its work drained: nothing of that communicator is in flight)
     for (int k = 0; k < n; k++) {
@@ -1240,12 +1246,14 @@ int gather_prepare(gpuart_hip_ctx *c, int which, float divide_by, int root, Gath
 /// stay uninitialised in the root's frame, rows rendered twice would depend on the order of the transfers.
 int check_shares(const std::vector<GatherHello> &all, int which, int root) {
     const gpuart_tile_geom &g0 = all[0].g;
+    // a rank that could not prepare says so before its (zeroed) share is looked at: rank 0's would otherwise read as a bad frame
+    for (size_t k = 0; k < all.size(); k++)
+        if (all[k].status) return fail(GPUART_HIP_ERR_DEVICE, "gather: rank " + std::to_string(k) + " could not prepare its share (its own call reports why)");
     // (before anything is sized by it: a share table is other ranks' — or a caller's — data)
     if (!geom_ok(g0) || g0.H > 65536 || g0.W > 65536) return fail(GPUART_HIP_ERR_ARG, "gather: inconsistent shares (frame of rank 0)");
     std::vector<uint8_t> cover(g0.H, 0);
     for (size_t k = 0; k < all.size(); k++) {
         const gpuart_tile_geom &g = all[k].g;
-        if (all[k].status) return fail(GPUART_HIP_ERR_DEVICE, "gather: rank " + std::to_string(k) + " could not prepare its share (its own call reports why)");
         if ((int)all[k].which != which || (int)all[k].root != root) return fail(GPUART_HIP_ERR_ARG, "gather: the ranks disagree about buffer or root");
         if (!geom_ok(g) || g.W != g0.W || g.H != g0.H) return fail(GPUART_HIP_ERR_ARG, "gather: inconsistent shares");
         if (g.th && (g.x0 != 0 || g.tw != g.W)) return fail(GPUART_HIP_ERR_ARG, "gather: shares must be full-width rows");
@@ -1463,6 +1471,9 @@ int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, fl
     // the stream, ahead of the bounded wait (the first version of this fix did exactly that; the test that holds the stream caught
     // it) — and a call that gives up leaves no queued copy pointing at memory the caller may free.
     if (c->h_frame_bytes < bytes) {
+        // (hipHostFree waits for the device: if an earlier read-out of this context gave up, its copy into h_frame may still be queued
+        // behind the stream that held it — that wait gets its bound first, and the buffer stays if the stream is still held)
+        if (c->h_frame && c->abandoned && (r = wait_stream(c, c->gather_timeout_ms, "gather: an abandoned read-back still owns the pinned frame buffer"))) return r;
         if (c->h_frame) { (void)hipHostFree(c->h_frame); c->h_frame = nullptr; c->h_frame_bytes = 0; }
         if (hipHostMalloc(&c->h_frame, bytes, hipHostMallocDefault) != hipSuccess) { c->h_frame = nullptr; return fail(GPUART_HIP_ERR_DEVICE, "gather: no pinned host memory for the frame"); }
         c->h_frame_bytes = bytes;
@@ -1549,7 +1560,7 @@ int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_op
             r = tile(k, g.tw, g.th);
             break;
         }
-        case 2: p.planned_passes = a; p.plan(); break;
+        case 2: p.set_plan(a); break;
         case 3:
             if (a > 5) return fail(GPUART_HIP_ERR_ARG, "bad mode");
             flush(k); p.mode = (int)a; p.plan();
@@ -1698,6 +1709,7 @@ int gpuart_hip_test_sort_tiles(gpuart_hip_ctx *c, const uint32_t *cost, size_t n
 // ---- phase watchdog and the bounded-call mechanism (bounded.h; pure host code) ----------------------------------------------
 int gpuart_hip_phase_begin(const char *name, uint32_t timeout_ms) { return bounded_ns::phase_begin(name, timeout_ms); }
 int gpuart_hip_phase_end(void) { return bounded_ns::phase_end(); }
+int gpuart_hip_phase_log(int on) { return bounded_ns::phase_log(on); }
 int gpuart_hip_comm_stuck(void) { return bounded_ns::stuck().load() ? 1 : 0; }
 int gpuart_hip_test_bounded_call(uint32_t hold_ms, uint32_t timeout_ms, int mark_stuck) {
     // (the helper's own `stuck` mark is global: the hook restores it unless the test wants to see the layer refuse its entry points)

@@ -30,6 +30,7 @@ struct RunPlanner {
     uint32_t max_batch = 1;       ///< passes a lane's buffers hold
     uint32_t lanes_in_use = 1;
     uint32_t planned_passes = 0;  ///< gpuart_hip_pt_plan hint (0: unknown)
+    size_t plan_done = 0;         ///< passes of the planned sequence launched so far (a sequence that completes is taken to repeat)
     int mode = 0;                 ///< gpuart_hip_set_mode
     size_t run_passes = 1;        ///< passes collected before a run starts by itself
     size_t pending = 0;           ///< passes collected, not launched yet
@@ -43,7 +44,7 @@ struct RunPlanner {
     /// A new tile: the run length the budgets allow and the lanes to try first. The caller allocates `lanes_in_use` lanes of
     /// `lane_bytes(max_batch)` and calls `shrink()` while the device refuses.
     void set_tile(uint32_t slots, size_t pixels) {
-        n_slots = slots; tile_pixels = pixels; pending = 0;
+        n_slots = slots; tile_pixels = pixels; pending = 0; plan_done = 0;
         if (!n_slots) { max_batch = 1; lanes_in_use = 1; run_passes = 1; return; }
         max_batch = (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)batch_limit, batch_paths / n_slots, RUN_KERNEL_SLOTS / n_slots}));
         first_lanes();
@@ -108,12 +109,20 @@ struct RunPlanner {
         }
     }
 
+    /// gpuart_hip_pt_plan: the caller expects `passes` passes before it observes the result (0: unknown).
+    void set_plan(uint32_t passes) { planned_passes = passes; plan_done = 0; plan(); }
+    void launched(size_t count) {
+        plan_done += count;
+        if (planned_passes && plan_done >= planned_passes) plan_done = 0;  // the sequence is complete: the next pass begins the next one
+    }
+
     /// One more pass was collected. Returns how many pending passes start NOW as one run (0: keep collecting).
     size_t on_pass() {
         pending++;
         if (pending < run_passes && pending < max_batch) return 0;
         const size_t count = pending;
         pending = 0;
+        launched(count);
         return count;
     }
 
@@ -125,14 +134,16 @@ struct RunPlanner {
         if (!pending) return runs;
         size_t n = uses_run_kernel(pending) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)lanes_in_use, pending, pending * n_slots / std::max<size_t>(1, min_run_paths)}));
         // the remainder of a PLANNED sequence is the plan's last, shorter run: cut up it would take lanes the plan left alone (20 passes =
-        // 6 x 3 + 2: a seventh run, not a seventh and an eighth)
-        if (planned_passes && !plan_run_factor && pending <= run_passes) n = 1;
+        // 6 x 3 + 2: a seventh run, not a seventh and an eighth). Only the plan's TAIL: what a read-back or a state change in the middle
+        // of the sequence flushes — or passes nobody planned — is spread over the lanes as before.
+        if (planned_passes && !plan_run_factor && pending <= run_passes && plan_done + pending == planned_passes) n = 1;
         n = std::max(n, (pending + max_batch - 1) / max_batch);
         for (size_t k = 0, first = 0; k < n; k++) {
             const size_t count = (pending - first) / (n - k);
             runs.push_back(count);
             first += count;
         }
+        launched(pending);
         pending = 0;
         return runs;
     }

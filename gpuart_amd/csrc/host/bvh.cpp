@@ -37,6 +37,22 @@ int build_threads() {
 #endif
     return (int)std::min(32u, std::max(1u, n));
 }
+
+/// Runs body(k, parts) for k in [0, parts) on `parts` threads (the caller's included).
+template <class F>
+void parallel_parts(int parts, F body) {
+    parts = std::max(1, parts);
+    std::vector<std::future<void>> tasks;
+    for (int k = 1; k < parts; k++) {
+        try {
+            tasks.push_back(std::async(std::launch::async, body, k, parts));
+        } catch (const std::system_error &) {
+            body(k, parts);
+        }
+    }
+    body(0, parts);
+    for (auto &t : tasks) t.get();
+}
 }  // namespace
 
 BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &primitives, unsigned maxNumLevels,
@@ -44,49 +60,41 @@ BoundingVolumesHierarchy::BoundingVolumesHierarchy(std::vector<Primitive *> &pri
     NumPrimitives = primitives.size();
     // the build sorts (box, pointer) items instead of chasing the pointers in every comparison; std::sort's sequence of
     // moves depends only on the comparison results, so the order is the one sorting the pointers would give
-    std::vector<Item> items(primitives.size());
-    for (size_t i = 0; i < primitives.size(); i++) {
-        const Primitive *p = primitives[i];
-        items[i] = Item{{p->GetXmin(), p->GetYmin(), p->GetZmin()}, {p->GetXmax(), p->GetYmax(), p->GetZmax()}, primitives[i]};
-    }
-    Subtree root;
-    // threads are worth starting when the scene is large enough to pay for them
-    std::atomic<int> spare(primitives.size() >= 16384 ? build_threads() - 1 : 0);
     const bool timing = std::getenv("GPUART_HOST_TIMING") != nullptr;
+    const auto tb = std::chrono::steady_clock::now();
+    // threads are worth starting when the scene is large enough to pay for them
+    const int threads = primitives.size() >= 16384 ? build_threads() : 1;
+    ItemList items(primitives.size());
+    parallel_parts((int)std::min<size_t>((size_t)threads, primitives.size() / 8192 + 1), [&](int k, int parts) {
+        for (size_t i = primitives.size() * (size_t)k / parts, e = primitives.size() * (size_t)(k + 1) / parts; i < e; i++) {
+            const Primitive *p = primitives[i];
+            items[i] = Item{{p->GetXmin(), p->GetYmin(), p->GetZmin()}, {p->GetXmax(), p->GetYmax(), p->GetZmax()}, primitives[i]};
+        }
+    });
+    Subtree root;
+    std::atomic<int> spare(threads - 1);
     const auto t0 = std::chrono::steady_clock::now();
     SubdivideParallel(root, items, 0, items.size(), 0, maxNumLevels, minPrimitivesPerNode, spare);
     const auto t1 = std::chrono::steady_clock::now();
-    for (size_t i = 0; i < items.size(); i++) primitives[i] = items[i].p;  // the reference leaves the caller's list sorted too
-    Assemble(root, primitives.size() >= 16384 ? build_threads() : 1);
-    StoreLeaves(items, primitives.size() >= 16384 ? build_threads() : 1);
-    if (timing)
-        fprintf(stderr, "[gpuart] BVH build: subdivide %.1f ms, leaf payloads %.1f ms (%d threads)\n",
-                std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), build_threads());
-}
-
-namespace {
-/// Runs body(k) for k in [0, parts) on `parts` threads (the caller's included).
-template <class F>
-void parallel_parts(int parts, F body) {
-    std::vector<std::future<void>> tasks;
-    for (int k = 1; k < parts; k++) {
-        try {
-            tasks.push_back(std::async(std::launch::async, body, k));
-        } catch (const std::system_error &) {
-            body(k);
-        }
+    // the reference leaves the caller's list sorted too
+    parallel_parts((int)std::min<size_t>((size_t)threads, primitives.size() / 65536 + 1), [&](int k, int parts) {
+        for (size_t i = items.size() * (size_t)k / parts, e = items.size() * (size_t)(k + 1) / parts; i < e; i++) primitives[i] = items[i].p;
+    });
+    Assemble(root, threads);
+    const auto t2 = std::chrono::steady_clock::now();
+    StoreLeaves(items, threads);
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[gpuart] BVH build: boxes %.1f ms, subdivide %.1f ms, assemble %.1f ms, leaf payloads %.1f ms (%d threads)\n",
+                ms(tb, t0), ms(t0, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()), threads);
     }
-    body(0);
-    for (auto &t : tasks) t.get();
 }
-}  // namespace
 
-void BoundingVolumesHierarchy::StoreLeaves(const std::vector<Item> &prims, int threads) {
+void BoundingVolumesHierarchy::StoreLeaves(const ItemList &prims, int threads) {
     // payload length of every leaf: per primitive one type quad + 1..4 data quads (reference src/core.h:72-80)
     const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, Nodes.size() / 4096));
     std::vector<size_t> partLen((size_t)parts + 1, 0);
-    parallel_parts(parts, [&](int k) {  // lengths relative to the part's start ...
+    parallel_parts(parts, [&](int k, int) {  // lengths relative to the part's start ...
         const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
         size_t cursor = 0;
         for (size_t i = a; i < b; i++) {
@@ -99,7 +107,7 @@ void BoundingVolumesHierarchy::StoreLeaves(const std::vector<Item> &prims, int t
     });
     for (int k = 0; k < parts; k++) partLen[(size_t)k + 1] += partLen[(size_t)k];  // ... made absolute below
     LeafData.resize(partLen[(size_t)parts]);  // (not zeroed: every float is written by the part that owns it)
-    parallel_parts(parts, [&](int k) {
+    parallel_parts(parts, [&](int k, int) {
         const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
         for (size_t i = a; i < b; i++) { Nodes[i].dataBegin += partLen[(size_t)k]; Nodes[i].dataEnd += partLen[(size_t)k]; }
         Primitive::Data one;
@@ -114,7 +122,7 @@ void BoundingVolumesHierarchy::StoreLeaves(const std::vector<Item> &prims, int t
     });
 }
 
-bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to,
+bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, ItemList &prims, size_t from, size_t to,
                                            unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
                                            size_t &split, std::atomic<int> &spareThreads, Scratch &scratch) {
     if (level > out.depth) out.depth = level;
@@ -126,7 +134,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
         n.higher = 0; n.count = 0; n.primFirst = 0; n.dataBegin = n.dataEnd = 0;
         struct Box { float lo[3], hi[3]; };
         Box part[8];  // wide <= 8
-        parallel_parts(wide, [&](int w) {
+        parallel_parts(wide, [&](int w, int) {
             Box b;
             for (int k = 0; k < 3; k++) { b.lo[k] = 99.0e+29f; b.hi[k] = -99.0e+29f; }
             const size_t a = from + (to - from) * (size_t)w / wide, e = from + (to - from) * (size_t)(w + 1) / wide;
@@ -164,28 +172,42 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
     // The reference sorts with std::sort on the box centres, 0.5 * (min + max) with the sum taken in float and the rest in
     // double (src/bvh.cpp:96). Comparing the float sums gives the same answers, and sorting (key, position) pairs the same
     // sequence of moves as sorting the primitives themselves; exact_sort.h performs that sort, large ones in parallel.
+    bool ordered = false;  // no NaN among the keys: the sorted centres do not decrease
     {
         const size_t n = to - from;
         if (scratch.keys.size() < n) { scratch.keys.resize(n); scratch.items.resize(n); }
         SortKey *keys = scratch.keys.data();
-        parallel_parts(wide, [&](int w) {
+        parallel_parts(wide, [&](int w, int) {
             for (size_t i = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide; i < e; i++)
                 keys[i] = SortKey{prims[from + i].lo[axis] + prims[from + i].hi[axis], (uint32_t)i};
         });
-        ExactSort::Sort(keys, keys + n, spareThreads);
+        ordered = ExactSort::Sort(keys, keys + n, spareThreads);
         Item *sorted = scratch.items.data();
-        parallel_parts(wide, [&](int w) {
+        parallel_parts(wide, [&](int w, int) {
             for (size_t i = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide; i < e; i++) sorted[i] = prims[from + keys[i].index];
         });
-        parallel_parts(wide, [&](int w) {
+        parallel_parts(wide, [&](int w, int) {
             const size_t a = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide;
             std::copy(sorted + a, sorted + e, prims.begin() + from + a);
         });
     }
 
     const double middle = out.nodes[self].lo[axis] + 0.5 * range;
+    // the reference scans from the front for the first centre beyond the middle (src/bvh.cpp:104-111); over centres that do not
+    // decrease that is a binary search (the root of an 871 200-triangle mesh: 435 000 items of 32 bytes walked by one thread).
+    // NaN centres compare false wherever they stand: then the scan itself.
     split = from;
-    while (split < to && 0.5 * (prims[split].lo[axis] + prims[split].hi[axis]) <= middle) split++;
+    auto beyond = [&](size_t i) { return !(0.5 * (prims[i].lo[axis] + prims[i].hi[axis]) <= middle); };
+    if (ordered) {
+        size_t a = from, b = to;  // first i in [from, to] with beyond(i), to if none
+        while (a < b) {
+            const size_t m = a + (b - a) / 2;
+            if (beyond(m)) b = m;
+            else a = m + 1;
+        }
+        split = a;
+    } else
+        while (split < to && !beyond(split)) split++;
     if (to - from > 2) {  // a dominating box must not capture everything on one side
         if (split == from) split++;
         else if (split == to) split--;
@@ -193,7 +215,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, std::vec
     return false;
 }
 
-void BoundingVolumesHierarchy::Subdivide(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+void BoundingVolumesHierarchy::Subdivide(Subtree &out, ItemList &prims, size_t from, size_t to, unsigned level,
                                          unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent,
                                          bool isLower, Scratch &scratch) {
     const uint32_t self = (uint32_t)out.nodes.size();
@@ -208,7 +230,7 @@ void BoundingVolumesHierarchy::Subdivide(Subtree &out, std::vector<Item> &prims,
     Subdivide(out, prims, split, to, level + 1, maxNumLevels, minPrimitivesPerNode, self, false, scratch);
 }
 
-void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, std::vector<Item> &prims, size_t from, size_t to,
+void BoundingVolumesHierarchy::SubdivideParallel(Subtree &out, ItemList &prims, size_t from, size_t to,
                                                  unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
                                                  std::atomic<int> &spareThreads) {
     Scratch scratch;  // of this task: a node's sort buffers are reused by the nodes below it
@@ -273,7 +295,7 @@ void BoundingVolumesHierarchy::Assemble(Subtree &root, int threads) {
     Nodes.resize(total);
     Depth = depth;
     const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, links.size()));
-    parallel_parts(parts, [&](int k) {
+    parallel_parts(parts, [&](int k, int) {
         for (size_t li = (size_t)k; li < links.size(); li += (size_t)parts) {
             const Link &l = links[li];
             const Subtree &p = *l.piece;
@@ -306,7 +328,7 @@ void BoundingVolumesHierarchy::Compile(Primitive::Data &out) const {
     out.resize(cursor * RGBA_ELEMS);
     float *const dst = out.data();
     const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)(Nodes.size() >= 65536 ? build_threads() : 1), Nodes.size() / 4096));
-    parallel_parts(parts, [&](int k) {
+    parallel_parts(parts, [&](int k, int) {
         const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
         for (size_t i = a; i < b; i++) {
             const Node &n = Nodes[i];

@@ -63,6 +63,15 @@ private:
         float lo[3], hi[3];
         Primitive *p;
     };
+    /// std::allocator whose value-less construct() leaves trivial elements uninitialised: a large buffer is then touched for the
+    /// first time by the threads that fill it, not zeroed by one thread beforehand.
+    template <class T>
+    struct UninitAlloc : std::allocator<T> {
+        template <class U> struct rebind { using other = UninitAlloc<U>; };
+        template <class U> void construct(U *p) { ::new ((void *)p) U; }
+        template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+    };
+    using ItemList = std::vector<Item, UninitAlloc<Item>>;  ///< (filled by the threads that compute the boxes, not zeroed first)
     /// Sort buffers of one build task (exact_sort.h keys, the permuted primitives), grown on demand.
     struct Scratch {
         std::vector<SortKey> keys;
@@ -82,32 +91,24 @@ private:
     /// Lays the pieces of a parallel build out in pre-order as `Nodes` (indices made absolute; several threads).
     void Assemble(Subtree &root, int threads);
     /// Serialises the primitives of all leaves into LeafData (Primitive::StoreIntoBVH), several threads on node ranges.
-    void StoreLeaves(const std::vector<Item> &prims, int threads);
+    void StoreLeaves(const ItemList &prims, int threads);
     std::vector<Node> Nodes;          ///< pre-order
-    /// std::allocator whose value-less construct() leaves trivial elements uninitialised: a large buffer is then touched for the
-    /// first time by the threads that fill it, not zeroed by one thread beforehand.
-    template <class T>
-    struct UninitAlloc : std::allocator<T> {
-        template <class U> struct rebind { using other = UninitAlloc<U>; };
-        template <class U> void construct(U *p) { ::new ((void *)p) U; }
-        template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
-    };
     std::vector<float, UninitAlloc<float>> LeafData;  ///< serialised primitives of all leaves, in leaf order
     size_t NumPrimitives = 0;
     unsigned Depth = 0;
 
     /// Sequential build of [from, to) appended to `out` (reference src/bvh.cpp:35-152).
-    static void Subdivide(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+    static void Subdivide(Subtree &out, ItemList &prims, size_t from, size_t to, unsigned level,
                           unsigned maxNumLevels, unsigned minPrimitivesPerNode, uint32_t parent, bool isLower, Scratch &scratch);
     /// The same tree, built in parallel: the two halves of large nodes by different threads, and the sort
     /// of a large node itself by several (exact_sort.h: libstdc++'s introsort, re-scheduled). `spareThreads` = threads
     /// that may still be started, shared by both. Byte-identical to the sequential build: every node's permutation is
     /// the one std::sort produces, the halves work on disjoint ranges of `prims`.
-    static void SubdivideParallel(Subtree &out, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+    static void SubdivideParallel(Subtree &out, ItemList &prims, size_t from, size_t to, unsigned level,
                                   unsigned maxNumLevels, unsigned minPrimitivesPerNode, std::atomic<int> &spareThreads);
     /// Fills node `self` of `out` with the box of [from, to); returns true if it became a leaf, else sorts the range
     /// along the split axis and returns the split position.
-    static bool PrepareNode(Subtree &out, uint32_t self, std::vector<Item> &prims, size_t from, size_t to, unsigned level,
+    static bool PrepareNode(Subtree &out, uint32_t self, ItemList &prims, size_t from, size_t to, unsigned level,
                             unsigned maxNumLevels, unsigned minPrimitivesPerNode, size_t &split, std::atomic<int> &spareThreads,
                             Scratch &scratch);
 };

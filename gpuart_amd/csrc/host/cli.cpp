@@ -89,9 +89,11 @@ int main(int argc, char **argv) {
     std::vector<std::unique_ptr<gpuart::Renderer>> rs;
     bool ok = true;
     for (unsigned g = 0; g < gpus && ok; g++) {
-        rs.emplace_back(new gpuart::Renderer(W, H, cam, (int)(device + g)));
+        // (GPUART_CLI_SHARED_DEVICE: every rank on --device — only an in-process RCCL stand-in accepts that: tests/test_gather_inprocess.py)
+        const unsigned dev = getenv("GPUART_CLI_SHARED_DEVICE") ? device : device + g;
+        rs.emplace_back(new gpuart::Renderer(W, H, cam, (int)dev));
         gpuart::Renderer &r = *rs.back();
-        if (!r.GetIsOK()) { std::cerr << "Renderer initialization failed on device " << device + g << "\n"; return 1; }
+        if (!r.GetIsOK()) { std::cerr << "Renderer initialization failed on device " << dev << "\n"; return 1; }
         r.SetUserSphere(Vec3f(us[0], us[1], us[2]), us[3], us[4]);
         if (nUs >= 6) r.SetUserSphereSpecular(us[5] != 0);
         if (nUs >= 7) r.SetUserSphereFuzzy(us[6] != 0);

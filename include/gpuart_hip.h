@@ -200,6 +200,9 @@ int gpuart_hip_comm_stuck(void);
  * creation, the gather and communicator destruction with it. */
 int gpuart_hip_phase_begin(const char *name, uint32_t timeout_ms);
 int gpuart_hip_phase_end(void);
+/* Phase lines on (1) / off (0) from now on, overriding GPUART_HIP_PHASE_LOG; returns the previous setting. The watchdog is not
+ * affected: a caller that brackets something inside a timed region (bench.py's gathers) keeps the bound and drops the two lines. */
+int gpuart_hip_phase_log(int on);
 /* Test hook of the mechanism behind the bounded RCCL calls (no device needed): a call that holds for hold_ms under a bound of
  * timeout_ms (0: inline, unbounded). 0 if it returned in time, GPUART_HIP_ERR_TIMEOUT otherwise; mark_stuck != 0 leaves the
  * communicator layer marked out of service as a real timeout does. */

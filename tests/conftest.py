@@ -21,10 +21,23 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=lambda it: it.get_closest_marker("rccl") is not None)   # stable: everything else keeps its order
 
 
+@pytest.fixture(scope="session")
+def rccl_stub(tmp_path_factory):
+    """tests/stubs/rccl_stub.cpp built as a shared library: the in-process RCCL stand-in (it links the HIP runtime; nothing of it runs
+    before a test's child process asks the product for a communicator with GPUART_HIP_RCCL_LIBRARY naming it)."""
+    import subprocess
+    d = tmp_path_factory.mktemp("rccl_stub")
+    so = str(d / "librccl_stub.so")
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", so,
+                           os.path.join(ROOT, "tests", "stubs", "rccl_stub.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return so
+
+
 # Since round 5 the product walks every tree in the reference's order (the only order proven to return the reference's winner; the
 # nearer-child-first walk of round 4 is opt-in: include/gpuart_hip.h, gpuart_hip_set_nearest_first). The suite tests the product's default.
 # GPUART_TEST_ORDER=nearest runs the WHOLE suite on the opt-in kernels instead — nearest-first on every regular tree, small ones included
-# — so that they keep being held against every golden vector and random scene (run once per round: profiles/r05/gpu_tests_nearest_first.txt;
+# — so that they keep being held against every golden vector and random scene (run once per round: profiles/r05/gpu_tests.txt;
 # tests/fuzz_parity.py renders every scene under both settings, and the tests that pin the opt-in walk ask for it themselves).
 if os.environ.get("GPUART_TEST_ORDER") == "nearest":
     os.environ.setdefault("GPUART_HIP_NEAREST_MIN_PRIMS", "0")

@@ -142,7 +142,20 @@ def main():
             same = (got[..., :3].view(np.uint32) == exp[..., :3].view(np.uint32)) | ((got[..., :3] == 0) & (exp[..., :3] == 0)) \
                 | (np.isnan(got[..., :3]) & np.isnan(exp[..., :3]))
             if not same.all() and GRAZING and what == "pt" and mode < 10 and mode % 10 != 2:
-                nf_differs = True  # (the first context walks nearest-first in modes 0 / 3; mode 2, the megakernel, keeps the reference's order)
+                # The first context walks nearest-first in modes 0 / 3 (mode 2, the megakernel, keeps the reference's order): a phantom hit
+                # it does not test is a known, counted difference — but only THAT is excused. A phantom changes the paths of the pixel it
+                # occurs in and nothing else, and both schedulers of the walk meet the same one: the scene passes iff the pipeline and
+                # k_run frames of the opt-in walk equal each other bit for bit and at most 0.5 % of the pixels (never fewer than 2 allowed)
+                # differ from the reference. Anything else is a regression of the opt-in kernels and fails.
+                other = res.get(("pt", 3 if mode % 10 == 0 else 0))
+                n_diff = int((~same.all(-1)).sum())
+                agree = other is not None and bool((other.view(np.uint32) == got.view(np.uint32)).all())
+                if agree and n_diff <= max(2, W * H // 200):
+                    nf_differs = True
+                    continue
+                print("seed %d: opt-in nearest-first walk, pt mode %d: %d of %d pixels differ and %s — not the signature of a phantom hit"
+                      % (seed, mode % 10, n_diff, W * H, "modes 0 and 3 agree" if agree else "modes 0 and 3 DISAGREE"), flush=True)
+                ok = False
                 continue
             if not same.all():
                 ok = False

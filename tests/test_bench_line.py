@@ -118,6 +118,15 @@ def test_roofline_block_from_stubbed_counters(tmp_path):
     assert ks[0]["valu_instr_per_pass"] == pytest.approx(5e8)
     # live HIP-event figures of the dominant kernel
     assert roof["kernel_avg_ms"] == pytest.approx(2.0) and roof["kernel_concurrency"] == pytest.approx(4.0)
+    # what binds: the largest like-by-like fraction, named; and the contract's per-launch fraction under both observed schedules
+    # (4e9 bytes per launch: 2.0 ms live -> 0.25; the trace child's launches average 1.5 ms x 60 -> 4e9 / 90 ms / 8e12)
+    b = roof["binding"]
+    assert set(b["candidates"]) == {"lane_slots", "l1_accesses", "node_visits", "l2_rate"}
+    assert b["frac"] == max(v for v in b["candidates"].values() if v is not None) and b["candidates"][b["resource"]] == b["frac"]
+    assert b["candidates"]["node_visits"] == roof["node_visits"]["frac"] and b["candidates"]["l2_rate"] == roof["hbm"]["algorithmic_rate_over_l2_peak"]
+    pr = roof["per_launch_frac_range"]
+    assert pr["timed_passes_hip_events"] == pytest.approx(0.25) and pr["rocprof_trace_child"] == pytest.approx(4.0e9 / (1.5e-3 * passes) / 8e12, abs=1e-4)
+    assert pr["min"] == min(pr["timed_passes_hip_events"], pr["rocprof_trace_child"]) and pr["max"] == max(pr["timed_passes_hip_events"], pr["rocprof_trace_child"])
     # a different number of profiled passes changes every per-pass figure: the denominator is the children's own pass count
     half = BL.assemble_roofline(ms, passes // 2, prof, trace, executed={"nodes": 1.6e8, "steps": 0.79e8, "algorithmic_bytes": 8.0e9},
                                 reference={"nodes": 2.8e8, "algorithmic_bytes": 15.0e9}, kernel_events=(400.0, 200, 0.1), passes_timed=100)

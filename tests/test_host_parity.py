@@ -213,6 +213,9 @@ def _sort_cases():
     k[0::2][:half] = np.arange(1, half + 1)
     k[1::2][:half] = np.arange(half + 1, 2 * half + 1) if m % 2 == 0 else 0
     yield "median-of-3 killer", k
+    # many tasks in the sort's pool at once (ranges above 16384 elements are tasks), half of the adjacent keys tied as in a quad mesh
+    big = np.repeat(rng.uniform(-1, 1, 300000).astype(np.float32), 2)
+    yield "600000 keys, every key twice", big[rng.permutation(big.size)]
     for size in (0, 1, 2, 3, 15, 16, 17, 31, 33, 100, 1000, 16385, 40000):
         yield "size %d" % size, np.round(rng.uniform(0, 8, size), 1)
 

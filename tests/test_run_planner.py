@@ -100,6 +100,15 @@ def test_a_planned_sequence_is_cut_into_as_many_equal_runs_as_there_are_lanes():
     assert lengths(25) == [4] * 6 + [1] and lengths(9) == [2, 2, 2, 2, 1]
     assert lengths(72) == [5] * 14 + [2] and lengths(128) == [8] * 16    # two rounds of 8 runs, never 9 runs of 8
     assert lengths(20, share=4) == [4] * 5                                  # 0.52M paths per pass: not below 2M paths (4 passes) a run
+    # only the plan's TAIL stays one run: what a read-back in the middle of the sequence flushes, and passes nobody planned after the
+    # sequence is complete, are spread over the lanes (run_planner.h on_flush)
+    seq = lambda *ops: [r[3] for r in plan([(RESIZE, 1920, 1080), (MODE, 3, 0)] + list(ops), **new)]
+    assert seq((PLAN, 64, 0), (PASS, 13, 0), (FLUSH, 0, 0)) == [8, 1, 1, 1, 2]                       # 5 pending, mid-sequence: four runs
+    assert seq((PLAN, 64, 0), (PASS, 61, 0), (FLUSH, 0, 0))[-5:] == [8, 1, 1, 1, 2]                    # (still mid-sequence)
+    assert seq((PLAN, 13, 0), (PASS, 13, 0), (FLUSH, 0, 0)) == [2] * 6 + [1]                          # the tail: one run
+    assert seq((PLAN, 69, 0), (PASS, 69, 0), (FLUSH, 0, 0))[-2:] == [5, 4]                            # the tail of 69 = 13 x 5 + 4: one run of 4
+    assert seq((PLAN, 69, 0), (PASS, 69, 0), (FLUSH, 0, 0), (PASS, 4, 0), (FLUSH, 0, 0))[-4:] == [4, 1, 1, 2]  # 4 passes nobody planned
+    assert seq((PLAN, 69, 0), (PASS, 69, 0), (FLUSH, 0, 0), (PASS, 69, 0), (FLUSH, 0, 0))[-2:] == [5, 4]     # the same sequence again
     # the rule of rounds 2-4 is still there for A/B (GPUART_HIP_PLAN_RUN_PERCENT=75)
     ops = [(RESIZE, 1920, 1080), (MODE, 3, 0), (PLAN, 24, 0), (PASS, 24, 0), (FLUSH, 0, 0)]
     assert [r[3] for r in plan(ops, plan_percent=75, lane_budget_mb=32768)] == [3] * 8

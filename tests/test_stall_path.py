@@ -4,7 +4,7 @@ The path gpuart_cli --gpus N takes — ncclCommInitAll -> gpuart_hip_gather_all_
 with its ptracingNormalize draw (src/renderer.cpp:601-616) inside the loop of src/main.cpp:549-599 — had three waits without a bound,
 and one child of round 4 did not end. Here every one of them is HELD and must come back within its bound:
   * without a GPU: the mechanism (a held call under gpuart_hip's bounded(), the phase watchdog's exit);
-  * on the GPU (-m gpu, marked rccl: they run last): the real entry points against tests/stubs/rccl_stub.c — an RCCL stand-in whose
+  * on the GPU (-m gpu, marked rccl: they run last): the real entry points against tests/stubs/rccl_stub.cpp — an RCCL stand-in whose
     ncclCommInitAll / ncclGroupEnd / ncclCommDestroy can be told never to return — and the read-back wait of gpuart_hip_gather_all_read
     against a stream held by gpuart_hip_test_stall; then gpuart_cli as a child process in each of those situations.
 Nothing here tries to make the round-4 stall show again."""
@@ -106,11 +106,8 @@ print("alive")
 
 # ---- the real entry points, on the GPU, against the stand-in RCCL ----------------------------------------------------------------
 @pytest.fixture(scope="module")
-def stub(tmp_path_factory):
-    d = tmp_path_factory.mktemp("rccl_stub")
-    so = str(d / "librccl_stub.so")
-    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tests", "stubs", "rccl_stub.c")])
-    return so
+def stub(rccl_stub):
+    return rccl_stub
 
 
 _SETUP = """

@@ -22,7 +22,7 @@ int main() {
     assert(t.timed_out && stuck().load() && stuck_in() == "slow");
     Outcome again = bounded("after", 1000, [](std::string &d) { d = "ok"; return 7; });
     assert(!again.timed_out && again.rc == 7);
-    // several callers at once (serialised inside; none may lose its result)
+    // several callers at once (each on its own helper; none may lose its result)
     std::vector<std::thread> th;
     std::atomic<int> sum{0};
     for (int k = 0; k < 8; k++)
@@ -38,6 +38,23 @@ int main() {
     for (int k = 0; k < 200; k++) { phase_begin("p", 5000); phase_end(); }
     for (auto &x : th) x.join();
     assert(sum == 160);
+    // calls that wait for EACH OTHER (every rank of a one-thread-per-rank process inside ncclCommInitRank): all must be inside at once
+    {
+        std::vector<std::thread> ranks;
+        auto arrived = std::make_shared<std::atomic<int>>(0);
+        std::atomic<int> ok{0};
+        for (int k = 0; k < 6; k++)
+            ranks.emplace_back([arrived, &ok] {
+                Outcome o = bounded("rendezvous", 5000, [arrived](std::string &) {
+                    arrived->fetch_add(1);
+                    while (arrived->load() < 6) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                    return 0;
+                });
+                if (!o.timed_out) ok++;
+            });
+        for (auto &x : ranks) x.join();
+        assert(ok == 6);
+    }
     assert(!recent_errors().empty());
     std::this_thread::sleep_for(std::chrono::milliseconds(450));  // let the abandoned helper finish its sleep before exit
     printf("bounded.h: ok\n");
