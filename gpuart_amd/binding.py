@@ -1,5 +1,7 @@
 """ctypes bindings of lib/libgpuart.so (C++ host library, capi.h) and lib/libgpuart_hip.so
-(device back end, include/gpuart_hip.h). Plumbing only — no computation happens here."""
+(device back end, include/gpuart_hip.h). Plumbing only — no computation happens here.
+GPUART_LIBDIR selects another build of the pair: gpuart_amd/lib_test (the product + the test hooks of include/gpuart_hip_test.h:
+what tests/conftest.py chooses), or an A/B variant under gpuart_amd/lib_ab/."""
 import ctypes as C
 import os
 
@@ -43,6 +45,20 @@ class Counters(C.Structure):
 
 _hip = None
 _host = None
+TEST_LIBDIR = os.path.join(HERE, "lib_test")  # the same sources + the hooks of include/gpuart_hip_test.h (csrc/Makefile)
+
+
+class _HipLibrary(C.CDLL):
+    """libgpuart_hip.so; says where the test hooks live when the product library is asked for one."""
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if name.startswith("gpuart_hip_test_"):
+                raise AttributeError("%s is a test hook (include/gpuart_hip_test.h): the product library %s has none — load the test build with "
+                                     "GPUART_LIBDIR=%s" % (name, self._name, TEST_LIBDIR)) from None
+            raise
 
 
 def hip_lib():
@@ -52,7 +68,7 @@ def hip_lib():
         if not os.path.exists(HIP_LIB):
             raise NativeLibraryMissing("%s not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
                                        "(make -C gpuart_amd/csrc); there is no CPU fallback" % HIP_LIB)
-        L = C.CDLL(HIP_LIB, mode=C.RTLD_GLOBAL)
+        L = _HipLibrary(HIP_LIB, mode=C.RTLD_GLOBAL)
         L.gpuart_hip_last_error.restype = C.c_char_p
         L.gpuart_hip_frame_row.restype = C.c_uint32
         _hip = L
@@ -111,6 +127,13 @@ def compile_bvh(descs, max_levels=1024, min_prims=2):
     out = np.ctypeslib.as_array(q, shape=(nq.value, 4)).copy()
     L.gpuart_free(q)
     return out, depth.value
+
+
+def last_build_ms():
+    """(build ms, compile ms) the host library itself spent in the last compile_bvh / compile_bvh_from_file of this process."""
+    out = (C.c_double * 2)()
+    host_lib().gpuart_last_build_ms(out)
+    return float(out[0]), float(out[1])
 
 
 def compile_bvh_from_file(kind, path, magnification=1.0, translation=(0, 0, 0), extra=()):

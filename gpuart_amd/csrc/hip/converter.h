@@ -175,7 +175,10 @@ struct Converter {
         uint32_t flags = bits(b[8]);
         if (flags & 0x80000000u) {
             uint32_t n = flags & ~0xE0000000u;
-            if (n_prims >= 0x0ffffff0u) { err = "too many primitives"; return false; }
+            // (a primitive's byte offset, 48 x index, and a record's, 64 x index, fit 32 bits: the kernels address both as base + 32-bit
+            //  offset, device_scene.h GD_ADDR32 — 89 million primitives / 67 million interior nodes; the reference's own format ends at
+            //  2^31 floats = 76 million triangles with their leaves)
+            if (n_prims >= 0x05555540u) { err = "too many primitives"; return false; }
             const uint32_t first = (uint32_t)n_prims;
             size_t a = addr + 3;
             static const int LEN[4] = {1, 2, 3, 4};
@@ -197,7 +200,7 @@ struct Converter {
         uint32_t lo = bits(b[9]), hi = bits(b[10]);
         if (lo != addr + 3) { err = "lower child does not follow its parent"; return false; }
         if (hi <= lo || hi >= nq) { err = "upper child address out of range"; return false; }
-        if (n_recs >= 0x0ffffff0u) { err = "too many nodes"; return false; }
+        if (n_recs >= 0x03fffff0u) { err = "too many nodes"; return false; }
         table[index].ref = (uint32_t)n_recs++;
         uint32_t lo_index, hi_index;
         size_t lo_end = 0;

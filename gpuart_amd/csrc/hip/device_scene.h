@@ -103,6 +103,13 @@ enum { P_SPHERE = 0, P_DISC = 1, P_TRIANGLE = 2, P_CONE = 3 };
 #ifndef GD_CERT_HITS
 #define GD_CERT_HITS 1
 #endif
+// Round 6, the step's bookkeeping (profiles/r06/step_isa_budget.txt); both bit-identical by construction, 0 = the code of round 5 for A/B:
+#ifndef GD_POP_WHOLE
+#define GD_POP_WHOLE 1     ///< TravStack::pop reads an entry's three words at once (one LDS round trip per accepted pop instead of two)
+#endif
+#ifndef GD_ADDR32
+#define GD_ADDR32 1        ///< node records / triangle leaves addressed as base + 32-bit byte offset (converter.h bounds both arrays below 4 GB)
+#endif
 #ifndef GD_QUICK_BOXES
 #define GD_QUICK_BOXES 1   ///< fast-form box tests try the quick answer of box_quick.h first (0: always the six face tests; A/B builds)
 #endif
@@ -425,7 +432,12 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, Trav &t, Wor
     uint32_t count = 1;
     for (uint32_t i = 0; i < count; i++) {
         uint32_t pi = first + i;
+#if GD_ADDR32
+        const float4 *pp = (const float4 *)((const char *)sc.prims + pi * 48u);
+        float4 q0 = pp[0], q1 = pp[1], q2 = pp[2];
+#else
         float4 q0 = sc.prims[3 * (size_t)pi], q1 = sc.prims[3 * (size_t)pi + 1], q2 = sc.prims[3 * (size_t)pi + 2];
+#endif
         if (i == 0) {
             count = __float_as_uint(q0.w) >> 2;
             if (count == 0) break;  // empty leaf (empty scene)
@@ -444,7 +456,11 @@ GD_FN bool leaf_test(const Scene &sc, const Ray &r, uint32_t first, Trav &t, Wor
 /// vector-memory request pipeline). The first one wins ties (`pos < closest` is strict), as in the reference's loop.
 template <bool ANY_HIT, bool COUNT, bool NEAREST = false>
 GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool two, Trav &t, WorkCounters *wc) {
+#if GD_ADDR32
+    const float4 *pa = (const float4 *)((const char *)sc.prims + first * 48u);
+#else
     const float4 *pa = sc.prims + 3 * (size_t)first;
+#endif
     const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
     if (COUNT) wc->prims[P_TRIANGLE] += two ? 2 : 1;
     float tb = -1.0f;
@@ -471,7 +487,11 @@ GD_FN bool leaf_test_tris(const Scene &sc, const Ray &r, uint32_t first, bool tw
 /// primitive, and nothing waits for the count in the first record. Same tests in the same order as the loop of `leaf_test`.
 template <bool ANY_HIT, bool COUNT, int TYPES = GD_ALL_TYPES, bool NEAREST = false>
 GD_FN bool leaf_test_small(const Scene &sc, const Ray &r, uint32_t first, bool two, Trav &t, WorkCounters *wc) {
+#if GD_ADDR32
+    const float4 *pa = (const float4 *)((const char *)sc.prims + first * 48u);
+#else
     const float4 *pa = sc.prims + 3 * (size_t)first;
+#endif
     const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
     float tb = -1.0f;
     F3 p, n; int ptype;
@@ -569,6 +589,12 @@ struct TravStack {
         uint2 a = ring_a[o];
         StackEntry e;
         e.ref = a.x; e.pe = __uint_as_float(a.y); e.he = ring_b[o];
+#if GD_POP_WHOLE
+        // Keep the entry's three words in the two LDS reads issued here: left alone the compiler reads the parameters first (4 + 4 bytes),
+        // compares, and fetches the ref with a THIRD read once the entry is accepted — a second LDS round trip in the dependent chain
+        // pop -> enter -> record address -> fetch of every step that ends in a pop.
+        asm volatile("" : "+v"(e.ref), "+v"(e.pe), "+v"(e.he));
+#endif
         return e;
     }
 };
@@ -703,7 +729,13 @@ GD_FN void trav_init(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack 
 template <bool COUNT, int BOXES = GD_BOXES_RUNTIME, bool NEAREST = false>
 GD_FN void trav_step_box(const Scene &sc, const Ray &r, F3 rdiv, Trav &t, TravStack &st, WorkCounters *wc, bool ordered = true) {
     static_assert(!NEAREST || BOXES == GD_BOXES_FAST, "nearest-first walks are for trees of regular boxes");
+#if GD_ADDR32
+    // (the uploader refuses trees beyond 2^26 records: a record's byte offset fits 32 bits, and base + zero-extended offset is an
+    // addressing mode of the load itself — no 64-bit address arithmetic per step, one address register instead of two)
+    const float4 *rec = (const float4 *)((const char *)sc.recs + (uint32_t)(t.node << 6));
+#else
     const float4 *rec = sc.recs + 4 * (size_t)t.node;
+#endif
     float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
     // Keep the two child refs in the 16-byte loads: without this the compiler narrows the loads to 12 bytes and
     // fetches a ref with a separate, dependent 4-byte load inside the branch that needs it (one more memory

@@ -17,10 +17,13 @@
 
 #include "device_shade.h"
 #include "gpuart_hip.h"
+#include "gpuart_hip_test.h"
 
 #include "kernels_pipeline.h"
 #include "kernel_run.h"
-#include "kernels_test.h"
+#ifdef GPUART_HIP_TEST_HOOKS
+#include "kernels_test.h"  // kernels of the device-function hooks (include/gpuart_hip_test.h)
+#endif
 #include "converter.h"
 #include "gather.h"
 #include "run_planner.h"
@@ -1336,6 +1339,7 @@ int gather_place(gpuart_hip_ctx *c, const std::vector<GatherHello> &all, float4 
 }  // namespace
 }  // extern "C++"
 
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *status, int n, int which, int root) {
     if (!shares || n < 1 || n > 1024) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     try {
@@ -1351,6 +1355,7 @@ int gpuart_hip_test_share_table(const gpuart_tile_geom *shares, const uint32_t *
         return fail(GPUART_HIP_ERR_ARG, std::string("share table: ") + e.what());
     }
 }
+#endif
 
 int gpuart_hip_comm_library(char *path, size_t size) {
     if (!path || size < 2) return fail(GPUART_HIP_ERR_ARG, "bad argument");
@@ -1485,6 +1490,7 @@ int gpuart_hip_gather_all_read(gpuart_hip_ctx *const *ctxs, int n, int which, fl
 }
 
 // ---- uploader hook: what gpuart_hip_upload_bvh decides about a tree, without a device (include/gpuart_hip.h) ----------
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flags) {
     if (!quads || !nquads || !flags) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     try {
@@ -1498,7 +1504,9 @@ int gpuart_hip_test_tree_class(const float *quads, size_t nquads, uint32_t *flag
         return fail(GPUART_HIP_ERR_ARG, std::string("tree: ") + e.what());
     }
 }
+#endif
 
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_tree_slack(const float *quads, size_t nquads, float *slack) {
     if (!quads || !nquads || !slack) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     try {
@@ -1512,8 +1520,10 @@ int gpuart_hip_test_tree_slack(const float *quads, size_t nquads, float *slack) 
         return fail(GPUART_HIP_ERR_ARG, std::string("tree: ") + e.what());
     }
 }
+#endif
 
 // ---- run planner hook: the planner of the context, driven without a device (include/gpuart_hip.h) ---------------------
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_ops, uint32_t *runs, int max_runs) {
     if (!cfg || (!ops && n_ops) || n_ops < 0 || (!runs && max_runs) || max_runs < 0) return fail(GPUART_HIP_ERR_ARG, "bad argument");
     RunPlanner p;
@@ -1580,10 +1590,12 @@ int gpuart_hip_test_planner(const uint32_t cfg[8], const uint32_t *ops, int n_op
     }
     return n_runs;
 }
+#endif
 
 // ---- test hooks ------------------------------------------------------------------------------------
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), 256, 0, c->stream
 
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_random(gpuart_hip_ctx *c, const float *in, int n, float *out) {
     const float *ins[] = {in}; float *outs[] = {out};
     return run_hook(c, n, ins, 1, outs, 1, [&](auto &i, auto &o) { k_test_random<<<GRID1(n)>>>(i[0], n, o[0]); });
@@ -1645,6 +1657,7 @@ int gpuart_hip_test_cam_rays(gpuart_hip_ctx *c, float *rstart, float *rdir) {
     Frame f = c->frame;
     return run_hook(c, n, nullptr, 0, outs, 2, [&](auto &, auto &o) { k_test_cam_rays<<<GRID1(n)>>>(f, o[0], o[1]); });
 }
+#endif
 
 namespace {
 /// One wave that keeps the stream busy for `ticks` of the 100 MHz wall clock (gpuart_hip_test_stall): it ends by itself.
@@ -1655,6 +1668,7 @@ __global__ void k_test_stall(unsigned long long ticks, unsigned long long *sink)
     if (sink && threadIdx.x == 0) *sink = n;
 }
 }  // namespace
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_tile_order(gpuart_hip_ctx *c, const uint32_t *order, size_t n) {
     if (!c || !c->frame.W) return fail(GPUART_HIP_ERR_ARG, "no frame size set");
     HIP_TRY(hipSetDevice(c->device));
@@ -1706,11 +1720,13 @@ int gpuart_hip_test_sort_tiles(gpuart_hip_ctx *c, const uint32_t *cost, size_t n
     HIP_TRY(e);
     return 0;
 }
+#endif
 // ---- phase watchdog and the bounded-call mechanism (bounded.h; pure host code) ----------------------------------------------
 int gpuart_hip_phase_begin(const char *name, uint32_t timeout_ms) { return bounded_ns::phase_begin(name, timeout_ms); }
 int gpuart_hip_phase_end(void) { return bounded_ns::phase_end(); }
 int gpuart_hip_phase_log(int on) { return bounded_ns::phase_log(on); }
 int gpuart_hip_comm_stuck(void) { return bounded_ns::stuck().load() ? 1 : 0; }
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_bounded_call(uint32_t hold_ms, uint32_t timeout_ms, int mark_stuck) {
     // (the helper's own `stuck` mark is global: the hook restores it unless the test wants to see the layer refuse its entry points)
     const bool was = bounded_ns::stuck().load();
@@ -1723,7 +1739,9 @@ int gpuart_hip_test_bounded_call(uint32_t hold_ms, uint32_t timeout_ms, int mark
     if (o.timed_out) return fail(GPUART_HIP_ERR_TIMEOUT, o.detail);
     return o.rc;
 }
+#endif
 
+#ifdef GPUART_HIP_TEST_HOOKS
 int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
     if (!c || ms > 5000) return fail(GPUART_HIP_ERR_ARG, "bad argument (at most 5000 ms)");
     HIP_TRY(hipSetDevice(c->device));
@@ -1731,6 +1749,7 @@ int gpuart_hip_test_stall(gpuart_hip_ctx *c, uint32_t ms) {
     HIP_TRY(hipGetLastError());
     return 0;
 }
+#endif
 
 #ifdef GD_STEP_STATS
 /// diagnostic builds only: reads (and clears) k_trace's step statistics (kernels_pipeline.h): box steps, lanes in them, leaf steps, lanes in

@@ -126,6 +126,9 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, ItemList
                                            unsigned level, unsigned maxNumLevels, unsigned minPrimitivesPerNode,
                                            size_t &split, std::atomic<int> &spareThreads, Scratch &scratch) {
     if (level > out.depth) out.depth = level;
+    static const bool phases = [] { const char *e = std::getenv("GPUART_HOST_TIMING"); return e && std::atoi(e) >= 2; }();
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;
     // the passes over a very large node's range (box, keys, permutation) run on several threads: with the subtrees assembled
     // once and the sort parallel, they are what is left of the top levels' critical path
     const int wide = to - from >= 262144 ? std::min(8, std::max(1, build_threads() / 4)) : 1;
@@ -154,6 +157,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, ItemList
                 if (part[w].hi[k] > n.hi[k]) n.hi[k] = part[w].hi[k];
             }
     }
+    if (phases) tp1 = std::chrono::steady_clock::now();
     const float xr = out.nodes[self].hi[0] - out.nodes[self].lo[0], yr = out.nodes[self].hi[1] - out.nodes[self].lo[1],
                 zr = out.nodes[self].hi[2] - out.nodes[self].lo[2];
 
@@ -181,7 +185,9 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, ItemList
             for (size_t i = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide; i < e; i++)
                 keys[i] = SortKey{prims[from + i].lo[axis] + prims[from + i].hi[axis], (uint32_t)i};
         });
+        if (phases) tp2 = std::chrono::steady_clock::now();
         ordered = ExactSort::Sort(keys, keys + n, spareThreads);
+        if (phases) tp3 = std::chrono::steady_clock::now();
         Item *sorted = scratch.items.data();
         parallel_parts(wide, [&](int w, int) {
             for (size_t i = n * (size_t)w / wide, e = n * (size_t)(w + 1) / wide; i < e; i++) sorted[i] = prims[from + keys[i].index];
@@ -192,6 +198,7 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, ItemList
         });
     }
 
+    if (phases) tp4 = std::chrono::steady_clock::now();
     const double middle = out.nodes[self].lo[axis] + 0.5 * range;
     // the reference scans from the front for the first centre beyond the middle (src/bvh.cpp:104-111); over centres that do not
     // decrease that is a binary search (the root of an 871 200-triangle mesh: 435 000 items of 32 bytes walked by one thread).
@@ -211,6 +218,11 @@ bool BoundingVolumesHierarchy::PrepareNode(Subtree &out, uint32_t self, ItemList
     if (to - from > 2) {  // a dominating box must not capture everything on one side
         if (split == from) split++;
         else if (split == to) split--;
+    }
+    if (phases && to - from >= 65536) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[gpuart] node level %u, %zu items (wide %d): box %.2f, keys %.2f, sort %.2f, permute %.2f, split %.2f ms\n", level, to - from, wide,
+                ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, tp4), ms(tp4, std::chrono::steady_clock::now()));
     }
     return false;
 }
@@ -314,19 +326,47 @@ void BoundingVolumesHierarchy::Assemble(Subtree &root, int threads) {
     });
 }
 
+size_t BoundingVolumesHierarchy::CompiledFloats() const {
+    // quad address of every node: 3 quads + its leaf payload, in pre-order (a running sum: parts sum their own nodes, the parts'
+    // totals are added up, every part shifts its addresses)
+    if (QuadAddr.size() == Nodes.size() + 1) return (size_t)QuadAddr.back() * RGBA_ELEMS;
+    QuadAddr.resize(Nodes.size() + 1);
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)(Nodes.size() >= 65536 ? build_threads() : 1), Nodes.size() / 16384));
+    std::vector<size_t> partLen((size_t)parts + 1, 0);
+    parallel_parts(parts, [&](int k, int) {
+        const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
+        size_t cursor = 0;
+        for (size_t i = a; i < b; i++) {
+            QuadAddr[i] = (uint32_t)cursor;
+            cursor += 3 + (Nodes[i].dataEnd - Nodes[i].dataBegin) / RGBA_ELEMS;
+        }
+        partLen[(size_t)k + 1] = cursor;
+    });
+    for (int k = 0; k < parts; k++) partLen[(size_t)k + 1] += partLen[(size_t)k];
+    assert(partLen[(size_t)parts] * RGBA_ELEMS <= (size_t)1 << 31);
+    parallel_parts(parts, [&](int k, int) {
+        if (!k) return;
+        const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
+        for (size_t i = a; i < b; i++) QuadAddr[i] += (uint32_t)partLen[(size_t)k];
+    });
+    QuadAddr[Nodes.size()] = (uint32_t)partLen[(size_t)parts];
+    return partLen[(size_t)parts] * RGBA_ELEMS;
+}
+
 void BoundingVolumesHierarchy::Compile(Primitive::Data &out) const {
     if (Nodes.empty()) return;
-    // quad address of every node: 3 quads + its leaf payload, in pre-order
     const size_t base = out.size() / RGBA_ELEMS;
-    std::vector<uint32_t> addr(Nodes.size());
-    size_t cursor = base;
-    for (size_t i = 0; i < Nodes.size(); i++) {
-        addr[i] = (uint32_t)cursor;
-        cursor += 3 + (Nodes[i].dataEnd - Nodes[i].dataBegin) / RGBA_ELEMS;
-    }
-    assert(cursor * RGBA_ELEMS <= (size_t)1 << 31);
-    out.resize(cursor * RGBA_ELEMS);
-    float *const dst = out.data();
+    const size_t n = CompiledFloats();
+    assert((base * RGBA_ELEMS + n) <= (size_t)1 << 31);
+    out.resize(base * RGBA_ELEMS + n);
+    CompileTo(out.data() + base * RGBA_ELEMS, base);
+}
+
+void BoundingVolumesHierarchy::CompileTo(float *dst, size_t baseQuad) const {
+    if (Nodes.empty()) return;
+    CompiledFloats();
+    const uint32_t base = (uint32_t)baseQuad;
+    const uint32_t *addr = QuadAddr.data();
     const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)(Nodes.size() >= 65536 ? build_threads() : 1), Nodes.size() / 4096));
     parallel_parts(parts, [&](int k, int) {
         const size_t a = Nodes.size() * (size_t)k / parts, b = Nodes.size() * (size_t)(k + 1) / parts;
@@ -334,11 +374,11 @@ void BoundingVolumesHierarchy::Compile(Primitive::Data &out) const {
             const Node &n = Nodes[i];
             float *q = dst + (size_t)addr[i] * RGBA_ELEMS;
             uint32_t flags = (n.isLower ? IS_LOWER : 0) | (i == 0 ? IS_ROOT : 0);
-            const float parentBits = as_float(i == 0 ? 0u : addr[n.parent]);
+            const float parentBits = as_float(i == 0 ? 0u : base + addr[n.parent]);
             q[0] = n.lo[0]; q[1] = n.lo[1]; q[2] = n.lo[2]; q[3] = RGBA_PAD;
             q[4] = n.hi[0]; q[5] = n.hi[1]; q[6] = n.hi[2]; q[7] = RGBA_PAD;
             if (n.count == 0 && n.higher != 0) {
-                q[8] = as_float(flags); q[9] = as_float(addr[i + 1]); q[10] = as_float(addr[n.higher]); q[11] = parentBits;
+                q[8] = as_float(flags); q[9] = as_float(base + addr[i + 1]); q[10] = as_float(base + addr[n.higher]); q[11] = parentBits;
             } else {
                 flags |= LEAF | (n.count & ~FLAGS_MASK);
                 q[8] = as_float(flags); q[9] = RGBA_PAD; q[10] = RGBA_PAD; q[11] = parentBits;

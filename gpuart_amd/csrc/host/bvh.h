@@ -40,6 +40,11 @@ public:
     ///               addresses in quads; the lower child follows its parent; leaves have lo = hi = 0.0f)
     ///   leaf data = per primitive {type,pad,pad,pad} + payload (Primitive::StoreIntoBVH)
     void Compile(Primitive::Data &compiledTree) const;
+    /// The same quads without the vector (whose resize zeroes 105 MB on one thread for an 871 200-triangle mesh before the threads
+    /// that fill it get to touch it): how many floats the compiled tree takes, and the tree written to `dst` (that many floats,
+    /// uninitialised memory is fine; `baseQuad` = the quad address the tree starts at, 0 for a tree on its own).
+    size_t CompiledFloats() const;
+    void CompileTo(float *dst, size_t baseQuad = 0) const;
 
     /// Prints a compiled tree, decoding it the way the device code does.
     static void Print(const Primitive::Data &compiledTree, std::ostream &s);
@@ -73,9 +78,9 @@ private:
     };
     using ItemList = std::vector<Item, UninitAlloc<Item>>;  ///< (filled by the threads that compute the boxes, not zeroed first)
     /// Sort buffers of one build task (exact_sort.h keys, the permuted primitives), grown on demand.
-    struct Scratch {
-        std::vector<SortKey> keys;
-        std::vector<Item> items;
+    struct Scratch {  // (not zeroed when they grow: every element in use is written first, by the threads that fill it)
+        std::vector<SortKey, UninitAlloc<SortKey>> keys;
+        ItemList items;
         void swap(Scratch &o) { keys.swap(o.keys); items.swap(o.items); }
     };
     /// A subtree under construction: nodes in pre-order with indices relative to the subtree (leaves refer to their
@@ -92,7 +97,8 @@ private:
     void Assemble(Subtree &root, int threads);
     /// Serialises the primitives of all leaves into LeafData (Primitive::StoreIntoBVH), several threads on node ranges.
     void StoreLeaves(const ItemList &prims, int threads);
-    std::vector<Node> Nodes;          ///< pre-order
+    std::vector<Node, UninitAlloc<Node>> Nodes;  ///< pre-order (every field of every node is written by Assemble's threads)
+    mutable std::vector<uint32_t, UninitAlloc<uint32_t>> QuadAddr;  ///< quad address of every node relative to the tree's first quad (CompiledFloats)
     std::vector<float, UninitAlloc<float>> LeafData;  ///< serialised primitives of all leaves, in leaf order
     size_t NumPrimitives = 0;
     unsigned Depth = 0;

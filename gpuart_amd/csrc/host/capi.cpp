@@ -67,24 +67,30 @@ void free_list(std::vector<Primitive *> &v) {
     v.clear();
 }
 
+double g_last_build_ms[2] = {0, 0};  ///< BoundingVolumesHierarchy's constructor, CompileTo — of the last compile_list (gpuart_last_build_ms)
+
 int compile_list(std::vector<Primitive *> &list, unsigned maxLevels, unsigned minPrims, float **quads, size_t *nquads,
                  unsigned *depth) {
     const bool timing = std::getenv("GPUART_HOST_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     BoundingVolumesHierarchy tree(list, maxLevels, minPrims);
     const auto t1 = std::chrono::steady_clock::now();
-    Primitive::Data data;
-    tree.Compile(data);
+    const size_t floats = tree.CompiledFloats();
+    *quads = (float *)malloc(floats * sizeof(float) + 16);
+    if (!*quads) return -1;
+    tree.CompileTo(*quads);
+    {
+        const auto t2 = std::chrono::steady_clock::now();
+        g_last_build_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        g_last_build_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
     if (timing) {
         const auto t2 = std::chrono::steady_clock::now();
         fprintf(stderr, "[gpuart] BVH of %zu primitives: build %.1f ms, compile %.1f ms\n", list.size(),
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
                 std::chrono::duration<double, std::milli>(t2 - t1).count());
     }
-    *quads = (float *)malloc(data.size() * sizeof(float) + 16);
-    if (!*quads) return -1;
-    memcpy(*quads, data.data(), data.size() * sizeof(float));
-    *nquads = data.size() / RGBA_ELEMS;
+    *nquads = floats / RGBA_ELEMS;
     if (depth) *depth = tree.GetDepth();
     return 0;
 }
@@ -149,6 +155,8 @@ void gpuart_sort_permutation(const float *keys, size_t n, unsigned threads, uint
 }
 
 void gpuart_free(void *p) { free(p); }
+
+void gpuart_last_build_ms(double out[2]) { out[0] = g_last_build_ms[0]; out[1] = g_last_build_ms[1]; }
 
 void gpuart_camera_basis(const float pos[3], const float dir[3], const float up[3], float fovY, float screenDist,
                          unsigned width, unsigned height, float out[13]) {

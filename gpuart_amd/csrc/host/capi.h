@@ -30,6 +30,10 @@ int gpuart_compile_bvh_from_file(int kind, const char *path, float magnification
                                  const gpuart_prim_desc *extra, int nextra, float **quads, size_t *nquads,
                                  unsigned *depth, size_t *nloaded);
 void gpuart_free(void *p);
+/* What the library itself spent in the last gpuart_compile_bvh / _from_file of this process: out[0] = BoundingVolumesHierarchy's
+ * constructor (the build), out[1] = its compilation into quads, in ms — without the harness around them (making and deleting one
+ * Primitive object per description, copying the result into the caller's language). */
+void gpuart_last_build_ms(double out[2]);
 /* The permutation the BVH build applies to a node's primitives: perm[i] = position (before sorting) of the element that
  * std::sort leaves at i when sorting by `keys` with operator< — computed by exact_sort.h on up to `threads` threads. */
 void gpuart_sort_permutation(const float *keys, size_t n, unsigned threads, uint32_t *perm);

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 
 #include "utils.h"
@@ -209,13 +210,16 @@ void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInf
         std::cout << "Compiling BVH tree... " << std::flush;
         t0 = std::chrono::high_resolution_clock::now();
     }
-    Primitive::Data compiled;
-    Tree.Compile(compiled);
+    // (the reference compiles into a Primitive::Data — src/renderer.cpp:460-466 —; the same quads go into a buffer that is not zeroed
+    // first: for an 871 200-triangle mesh that is 105 MB one thread would touch before the threads that fill it)
+    const size_t compiledFloats = Tree.CompiledFloats();
+    std::unique_ptr<float[]> compiled(new float[compiledFloats]);
+    Tree.CompileTo(compiled.get());
     const auto tCompiled = std::chrono::high_resolution_clock::now();
     if (printInfo) std::cout << "done (" << Utils::TimeElapsed(t0) << ").\n";
-    if (!Backend || !Check(gpuart_hip_upload_bvh(Backend, compiled.data(), compiled.size() / RGBA_ELEMS), "uploading the BVH"))
+    if (!Backend || !Check(gpuart_hip_upload_bvh(Backend, compiled.get(), compiledFloats / RGBA_ELEMS), "uploading the BVH"))
         IsOK = false;
-    if (printInfo) std::cout << "Compiled tree occupies " << ByteCount{compiled.size() * sizeof(float)} << "." << std::endl;
+    if (printInfo) std::cout << "Compiled tree occupies " << ByteCount{compiledFloats * sizeof(float)} << "." << std::endl;
     if (std::getenv("GPUART_HOST_TIMING")) {
         const auto tEnd = std::chrono::high_resolution_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The test suite runs on gpuart_amd/lib_test/: the product's sources compiled with -DGPUART_HIP_TEST_HOOKS (csrc/Makefile), i.e. the product
+# library + the gpuart_hip_test_* entry points of include/gpuart_hip_test.h that the parity tests call the device code through. The product
+# library itself (gpuart_amd/lib/: what gpuart_cli, bench.py and __graft_entry__.smoke() load) has none of them; the tests that start
+# gpuart_cli, and tests/test_product_library.py, run on that one. GPUART_LIBDIR set by the caller (an A/B build) wins.
+os.environ.setdefault("GPUART_LIBDIR", os.path.join(ROOT, "gpuart_amd", "lib_test"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "rccl: initialises an RCCL communicator on the GPU (run after everything else)")

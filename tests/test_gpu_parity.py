@@ -55,6 +55,23 @@ def test_native_library_is_the_one_running(B):
     assert "libgpuart_hip.so" in maps
 
 
+def test_the_product_library_runs_the_smoke_frame():
+    """The suite runs on gpuart_amd/lib_test (the product's sources + the test hooks, tests/conftest.py). The PRODUCT pair, gpuart_amd/lib —
+    no hook compiled in — is what this child loads (GPUART_LIBDIR removed): __graft_entry__.smoke(), direct lighting + two path-tracing
+    passes of the box scene through the C++ Renderer against the oracle, bit for bit; and it really is that library that ran."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "GPUART_LIBDIR"}
+    code = ("import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as g\ng.smoke()\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert '/gpuart_amd/lib/libgpuart_hip.so' in maps and '/gpuart_amd/lib/libgpuart.so' in maps and 'lib_test' not in maps, 'wrong library'\n"
+            "from gpuart_amd import binding as B\n"
+            "try:\n    B.hip_lib().gpuart_hip_test_planner\n    raise SystemExit('the product library has a test hook')\n"
+            "except AttributeError as e:\n    assert 'lib_test' in str(e)\nprint('product library ok')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "smoke OK" in p.stdout and "product library ok" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
 # ---- per-function hooks vs golden vectors ---------------------------------------------------------
 def test_hash_random(be):
     g = golden("hash")

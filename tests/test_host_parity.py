@@ -15,20 +15,41 @@ from tests.util import assert_bits, scene
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
+def _declared(header):
+    return sorted(set(re.findall(r"\b(gpuart_hip_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", header)).read())))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
 def test_c_abi_exports_every_declared_symbol():
-    L = B.hip_lib()
-    hdr = open(os.path.join(ROOT, "include", "gpuart_hip.h")).read()
-    names = sorted(set(re.findall(r"\b(gpuart_hip_[a-z_0-9]+)\s*\(", hdr)))
-    assert len(names) >= 25
+    """The PRODUCT library (gpuart_amd/lib/libgpuart_hip.so: what libgpuart.so, gpuart_cli, bench.py and smoke() load) exports exactly what
+    include/gpuart_hip.h declares — no test hook among it, and nothing else: a host program that defines `launch_run` or `check_shares` of
+    its own must not be interposed (the link uses csrc/hip/exports.map). The library the test suite runs on (gpuart_amd/lib_test/, the same
+    sources with -DGPUART_HIP_TEST_HOOKS) exports that plus exactly the hooks of include/gpuart_hip_test.h."""
+    import ctypes as C
+    product = os.path.join(ROOT, "gpuart_amd", "lib", "libgpuart_hip.so")
+    names, hooks = _declared("gpuart_hip.h"), [n for n in _declared("gpuart_hip_test.h") if n.startswith("gpuart_hip_test_")]
+    assert len(names) >= 25 and len(hooks) >= 15 and not [n for n in names if "_test_" in n]
+    assert _exported(product) == names, (sorted(set(_exported(product)) - set(names)), sorted(set(names) - set(_exported(product))))
+    L = C.CDLL(product)
     for n in names:
         assert hasattr(L, n), "libgpuart_hip.so does not export " + n
-    # ... and nothing else: a host program that defines `launch_run` or `check_shares` of its own must not be interposed
-    # (the link uses csrc/hip/exports.map)
+    tested = B.hip_lib()._name
+    if os.path.dirname(tested) == os.path.join(ROOT, "gpuart_amd", "lib_test"):   # (an A/B run names its own directory: GPUART_LIBDIR)
+        assert _exported(tested) == sorted(names + hooks)
+
+
+def test_the_product_host_library_and_cli_are_bound_to_the_product_library():
+    """gpuart_amd/lib/libgpuart.so and bin/gpuart_cli name libgpuart_hip.so as a dependency and find it beside themselves ($ORIGIN): never
+    the test build."""
     import subprocess
-    out = subprocess.run(["nm", "-D", "--defined-only", B.hip_lib()._name], capture_output=True, text=True, check=True).stdout
-    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
-    extra = [n for n in exported if n not in names]
-    assert not extra, "libgpuart_hip.so exports symbols the header does not declare: %s" % extra
+    for path, rpath in ((os.path.join(ROOT, "gpuart_amd", "lib", "libgpuart.so"), "$ORIGIN"), (os.path.join(ROOT, "gpuart_amd", "bin", "gpuart_cli"), "$ORIGIN/../lib")):
+        dyn = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
+        assert "libgpuart_hip.so" in dyn and rpath in dyn, dyn
 
 
 def test_host_c_api_exports():

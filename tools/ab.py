@@ -15,6 +15,7 @@ ap.add_argument("-r", type=int, default=4)
 ap.add_argument("names", nargs="+")
 a = ap.parse_args()
 res = {n: [] for n in a.names}
+frames = {n: set() for n in a.names}
 for _ in range(a.r):
     for n in a.names:
         env = dict(os.environ)
@@ -23,5 +24,8 @@ for _ in range(a.r):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_passes.py"), str(a.k), "3"], env=env,
                              capture_output=True, text=True, check=True).stdout
         res[n].append(min(float(x) for x in re.findall(r"([0-9.]+) ms/pass", out)))
+        frames[n].update(re.findall(r"frame ([0-9a-f]+)", out))
+print("frames: %s" % ("identical in every variant and round (%s)" % next(iter(frames[a.names[0]])) if len(set().union(*frames.values())) == 1
+                      else "DIFFER: %s" % {n: sorted(f) for n, f in frames.items()}), flush=True)
 for n in a.names:
     print("%-24s best %.3f  median %.3f ms/pass  %s" % (n, min(res[n]), statistics.median(res[n]), " ".join("%.3f" % x for x in res[n])), flush=True)

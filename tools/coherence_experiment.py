@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("GPUART_LIBDIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpuart_amd", "lib_test"))  # uses test hooks (include/gpuart_hip_test.h)
 import sys, os, numpy as np, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
 from gpuart_amd import binding as B, synth_scenes as S

@@ -5,6 +5,7 @@ then rounds of bounce rays off the hits (cosine-hemisphere directions from the d
 the population a path tracer produces. Disagreeing rays are printed and saved with the tree (npz) for a CPU post-mortem
 (tests/order_debug.py). No oracle involved.   python3 tools/order_rays.py SCENE [rounds] [out.npz]"""
 import os
+os.environ.setdefault("GPUART_LIBDIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpuart_amd", "lib_test"))  # uses test hooks (include/gpuart_hip_test.h)
 import sys
 
 import numpy as np

@@ -10,6 +10,7 @@ the parity tests; this tool only asks whether the two orders agree, at sizes the
             where a box is not conservative for its primitive in fp32 and the reference's own winner hinges on its visiting order)"""
 import argparse
 import os
+os.environ.setdefault("GPUART_LIBDIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpuart_amd", "lib_test"))  # uses test hooks (include/gpuart_hip_test.h)
 import sys
 import tempfile
 import time

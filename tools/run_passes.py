@@ -31,11 +31,15 @@ if int(os.environ.get("SHARE", "1")) > 1:  # SHARE=N: rank 0's share of the fram
     assert r.set_interleaved_tile(0, y0, W, rows, band, stride)
 r.backend.set_mode(int(os.environ.get('GPUART_MODE', '0')))
 r.backend.set_timing(int(os.environ.get('GPUART_TIMING', '0')))
+import numpy as np  # noqa: E402
 for _ in range(REPS):
+    r.set_seed(5489)  # the same RandSeeds in every repetition and every process: the frames of two builds can be compared
     r.restart_path_tracing(1, K)
     t0 = time.perf_counter()
     for _ in range(K):
         r.path_tracing_pass()
     r.finish()
     print("%d passes, %.3f ms/pass" % (K, (time.perf_counter() - t0) / K * 1e3))
+acc = r.read_radiance(False)
+print("frame %08x" % int(np.bitwise_xor.reduce((acc.view(np.uint32) * np.arange(1, acc.size + 1, dtype=np.uint32).reshape(acc.shape)).ravel())))
 r.close()

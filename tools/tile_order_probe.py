@@ -4,6 +4,7 @@ tile, row-major (as shipped) against sorted by an estimate of their cost, most e
 hook: a pixel that misses = 1, that hits a triangle = 5, anything else = 2). Accumulators must be equal bit for bit.
     python3 tools/tile_order_probe.py [WORKLOAD]     (TILE_N=1,8  K=1,2,20,64)"""
 import os
+os.environ.setdefault("GPUART_LIBDIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpuart_amd", "lib_test"))  # uses test hooks (include/gpuart_hip_test.h)
 import sys
 import time
 
