@@ -150,6 +150,21 @@ __global__ void __launch_bounds__(TO_THREADS) k_tile_order(uint32_t *__restrict_
     }
 }
 
+/// Lane 0's value in every lane, where all 64 lanes are active (the persistent loops' wave-uniform control flow). GD_UNIFORM = 1: through
+/// v_readfirstlane — a SCALAR the compiler knows to be the same in every lane, so that what is derived from it (the chunk bounds, `exhausted`)
+/// lives in scalar registers and wave-uniform branches on it are scalar branches; a shuffle (ds_bpermute, the code of rounds 1-5: 0) yields
+/// a vector value, the loop exits that test it became execution-mask arithmetic on both paths.
+#ifndef GD_UNIFORM
+#define GD_UNIFORM 1
+#endif
+GD_FN uint32_t wave_value(uint32_t v) {
+#if GD_UNIFORM
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return (uint32_t)__shfl(v, 0, 64);
+#endif
+}
+
 /// The traversal stack of this lane: its column of the wave's LDS ring, its column of the launch's spill area
 /// (`wave` of `total_lanes / 64` waves).
 GD_FN TravStack make_stack(uint2 *ring_a, float *ring_b, uint4 *spill, uint32_t total_lanes, uint32_t wave, uint32_t column) {
@@ -350,6 +365,9 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
 #define GD_SS_PHASE(acc)
 #endif
     for (;;) {
+#if GD_UNIFORM >= 2
+        chunk_next = wave_value(chunk_next); chunk_end = wave_value(chunk_end); M = wave_value(M); exhausted = wave_value(exhausted ? 1u : 0u) != 0;
+#endif
         // ---- refill idle lanes from the queue
         unsigned long long idle = __ballot(slot == SLOT_INVALID);
 #ifdef GD_STEP_STATS
@@ -360,7 +378,7 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
                 if (static_end >= q_end) { exhausted = true; break; }
                 uint32_t base = 0;
                 if (lane_id() == 0) base = atomicAdd(cursor, tune.chunk);
-                base = __shfl(base, 0, 64) + static_end;
+                base = wave_value(base) + static_end;
                 if (base >= q_end) { exhausted = true; break; }
                 chunk_next = base;
                 chunk_end = min(base + tune.chunk, q_end);
@@ -557,8 +575,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Scene sc, Frame f, gpuart_param
           if (n_next) base1 = atomicAdd(&b.counters[4 * (seg + 1)], n_next);
           if (n_shadow) base2 = atomicAdd(&b.counters[4 * seg + 2], n_shadow);
       }
-      base1 = __shfl(base1, 0, 64);
-      base2 = __shfl(base2, 0, 64);
+      base1 = wave_value(base1);
+      base2 = wave_value(base2);
       for (uint32_t i = threadIdx.x; i < n_next; i += BLOCK) next_queue[base1 + i] = stage_next[i];
       for (uint32_t i = threadIdx.x; i < n_shadow; i += BLOCK) b.shadow_queue[base2 + i] = stage_shadow[i];
       __syncthreads();
@@ -648,7 +666,7 @@ __global__ void __launch_bounds__(BLOCK, GD_DIRECT_WAVES) k_direct_persistent(Sc
                 if (static_end >= n) { exhausted = true; break; }
                 uint32_t base = 0;
                 if (lane_id() == 0) base = atomicAdd(cursor, tune.chunk);
-                base = __shfl(base, 0, 64) + static_end;
+                base = wave_value(base) + static_end;
                 if (base >= n) { exhausted = true; break; }
                 chunk_next = base;
                 chunk_end = min(base + tune.chunk, n);
