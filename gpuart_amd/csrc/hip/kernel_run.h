@@ -141,11 +141,6 @@ k_run(Scene sc, Frame f, gpuart_params P, SeedBatch seeds, PathBuffers b, int j,
     const unsigned long long tl_zero = g_run_hist[2 * 128 - 1];  // the host stores the launch's reference clock there (0: use own start)
 #endif
     for (;;) {
-#if GD_UNIFORM >= 2
-        // the wave-uniform bookkeeping, said to be uniform (no-ops where the compiler already keeps a value in a scalar register)
-        n_ready = wave_value(n_ready); n_shade = wave_value(n_shade); r_head = wave_value(r_head); n_live = wave_value(n_live); M = wave_value(M);
-        exhausted = wave_value(exhausted ? 1u : 0u) != 0; first_chunk = wave_value(first_chunk ? 1u : 0u) != 0;
-#endif
         bool start = false;  // this lane begins a query in this round
         // ---- a finished nearest-first query that cannot vouch for its answer walks again, in the reference's order (every replica alike)
         if (NEAR && ent != SLOT_INVALID && t.state == TRAV_DONE && trav_settle<NEAR>(t, !(ent & (RUN_F_SHADOW | RUN_F_REWALK)))) {
