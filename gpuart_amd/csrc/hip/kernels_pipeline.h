@@ -365,9 +365,6 @@ k_trace(Scene sc, Frame f, gpuart_params P, PathBuffers b, int seg_c, int seg_s,
 #define GD_SS_PHASE(acc)
 #endif
     for (;;) {
-#if GD_UNIFORM >= 2
-        chunk_next = wave_value(chunk_next); chunk_end = wave_value(chunk_end); M = wave_value(M); exhausted = wave_value(exhausted ? 1u : 0u) != 0;
-#endif
         // ---- refill idle lanes from the queue
         unsigned long long idle = __ballot(slot == SLOT_INVALID);
 #ifdef GD_STEP_STATS
