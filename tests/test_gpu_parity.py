@@ -639,6 +639,35 @@ def test_other_execution_modes_give_identical_frames(B, be, O, name, mode):
         be.set_mode(0)
 
 
+@pytest.mark.parametrize("mode", [3, 5])
+@pytest.mark.parametrize("name", ["frames_box_seg5", "frames_scene_d_seg8", "frames_tree_near_seg5"])
+def test_the_opt_in_nearest_first_kernels_on_the_goldens(B, O, name, mode):
+    """The opt-in walk (gpuart_hip_set_nearest_first: nearer child first + certificate + second walk) is still shipped: a few goldens of the
+    reference's GLSL through its pipeline and k_run variants in the DEFAULT suite, whatever GPUART_TEST_ORDER says (the whole suite runs on
+    it with GPUART_TEST_ORDER=nearest; tests/fuzz_parity.py renders every random scene under both settings). None of these scenes holds a
+    phantom hit, so the frames must equal the reference's."""
+    g = golden(name)
+    W, H = int(g["W"]), int(g["H"])
+    tree, _ = O.build_bvh(scene(str(g["scene"])))
+    b = B.Backend(0)
+    try:
+        b.resize(W, H); b.upload_bvh(tree); b.set_camera(g["cam"])
+        b.set_nearest_first(0)
+        assert b.scene_order() == 0
+        mk = frame_golden_params(O, g)
+        b.set_mode(mode)
+        if "direct" in g:
+            b.render_direct(to_params(B, mk()))
+            check_frame(b.read(0), g["direct"], "direct")
+        npass = int(g["npasses"]) if "npasses" in g else 2
+        b.pt_reset()
+        for k in range(npass):
+            b.pt_pass(to_params(B, mk()), g["seeds"][k], 1)
+        check_frame(b.read(1), g["pt_acc"], "PT accumulated, nearest-first walk, mode %d" % mode)
+    finally:
+        b.close()
+
+
 @pytest.mark.parametrize("k0", [0, -19])
 def test_deep_tree_frames(B, be, O, k0):
     """A 39-level tree (deeper than the LDS ring stack): frames through the spill path == oracle. k0 = 0: spheres out to 5e11,

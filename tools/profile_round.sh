@@ -20,6 +20,8 @@ timeout -k 10 400 python3 bench.py --frame 3840x2160 --steps 16 --warmup 4 > $OU
 timeout -k 10 400 python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile > $OUT/bench_steps1.json 2> $OUT/bench_steps1.err
 python3 tools/tile_overhead.py > $OUT/tile_scaling_one_gpu.txt 2>&1
 TILE_K=20 python3 tools/tile_overhead.py > $OUT/tile_scaling_one_gpu_k20.txt 2>&1
+# BASELINE.json's cfg5 as far as one GPU can show it: a rank's share of the 7680x4320 frame among 8 ranks, 256 passes, against the whole frame
+TILE_FRAME=7680x4320 TILE_K=256 TILE_N=1,8 TILE_REPS=2 python3 tools/tile_overhead.py > $OUT/tile_scaling_one_gpu_cfg5.txt 2>&1
 python3 tools/time_direct.py > $OUT/direct_lighting.txt 2>&1
 (python3 tools/bvh_build_time.py scene_d; python3 tools/bvh_build_time.py big; for s in scene_d big cluster tree; do python3 tools/setprims_time.py $s; done) > $OUT/bvh_build.txt 2>&1
 timeout -k 10 200 tools/ubench/ubench > $OUT/ubench.txt 2>&1
