@@ -643,6 +643,13 @@ class Renderer:
         return out
 
     def finish(self): return bool(self.L.gpuart_renderer_finish(self.h))
+
+    def last_setprims_ms(self):
+        """(whole call, BVH build, compilation, re-layout + upload) of the last set_primitives, ms, as the library timed them."""
+        out = (C.c_double * 4)()
+        self.L.gpuart_renderer_last_setprims_ms(self.h, out)
+        return tuple(float(x) for x in out)
+
     def save_checkpoint(self, path): return bool(self.L.gpuart_renderer_save_checkpoint(self.h, path.encode()))
     def load_checkpoint(self, path): return bool(self.L.gpuart_renderer_load_checkpoint(self.h, path.encode()))
 

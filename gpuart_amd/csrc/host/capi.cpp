@@ -232,6 +232,10 @@ int gpuart_renderer_save_checkpoint(gpuart_renderer *r, const char *path) { retu
 int gpuart_renderer_load_checkpoint(gpuart_renderer *r, const char *path) { return r->impl.LoadCheckpoint(path) ? 1 : 0; }
 gpuart_hip_ctx *gpuart_renderer_backend(gpuart_renderer *r) { return r->impl.GetBackend(); }
 void gpuart_renderer_params(gpuart_renderer *r, gpuart_params *out) { *out = r->impl.MakeParams(); }
+void gpuart_renderer_last_setprims_ms(gpuart_renderer *r, double out[4]) {
+    for (int k = 0; k < 4; k++) out[k] = r->impl.GetLastSetPrimitivesMs()[k];
+}
+
 void gpuart_renderer_scene_info(gpuart_renderer *r, uint64_t *nodes, uint64_t *prims, unsigned *depth) {
     const BoundingVolumesHierarchy &t = r->impl.GetBVH();
     if (nodes) *nodes = t.GetNumNodes();

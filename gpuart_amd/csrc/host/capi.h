@@ -79,6 +79,8 @@ int gpuart_renderer_save_checkpoint(gpuart_renderer *r, const char *path);
 int gpuart_renderer_load_checkpoint(gpuart_renderer *r, const char *path);
 gpuart_hip_ctx *gpuart_renderer_backend(gpuart_renderer *r);
 void gpuart_renderer_params(gpuart_renderer *r, gpuart_params *out);
+/* What the renderer's last SetPrimitives spent inside the library, ms: whole call, BVH build, compilation, re-layout + upload. */
+void gpuart_renderer_last_setprims_ms(gpuart_renderer *r, double out[4]);
 void gpuart_renderer_scene_info(gpuart_renderer *r, uint64_t *nodes, uint64_t *prims, unsigned *depth);
 
 #ifdef __cplusplus

@@ -220,9 +220,11 @@ void Renderer::SetPrimitives(std::vector<Primitive *> &primitives, bool printInf
     if (!Backend || !Check(gpuart_hip_upload_bvh(Backend, compiled.get(), compiledFloats / RGBA_ELEMS), "uploading the BVH"))
         IsOK = false;
     if (printInfo) std::cout << "Compiled tree occupies " << ByteCount{compiledFloats * sizeof(float)} << "." << std::endl;
+    const auto tEnd = std::chrono::high_resolution_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    LastSetPrimitivesMs[0] = ms(tAll, tEnd); LastSetPrimitivesMs[1] = ms(tAll, tBuilt); LastSetPrimitivesMs[2] = ms(tBuilt, tCompiled);
+    LastSetPrimitivesMs[3] = ms(tCompiled, tEnd);
     if (std::getenv("GPUART_HOST_TIMING")) {
-        const auto tEnd = std::chrono::high_resolution_clock::now();
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[gpuart] Renderer::SetPrimitives(%zu primitives): %.1f ms (build %.1f + compile %.1f + re-layout and upload %.1f)\n",
                 primitives.size(), ms(tAll, tEnd), ms(tAll, tBuilt), ms(tBuilt, tCompiled), ms(tCompiled, tEnd));
     }

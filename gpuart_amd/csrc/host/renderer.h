@@ -119,6 +119,8 @@ public:
     /// after LoadCheckpoint to render on to more paths per pixel than the checkpointed run asked for.
     void ExtendPathTracing(unsigned pathsPerPass, unsigned pathsPerPixel);
     gpuart_hip_ctx *GetBackend() const { return Backend; }
+    /// What the last SetPrimitives spent, in ms: the whole call, the BVH build, its compilation, re-layout + upload (for tools/setprims_time.py).
+    const double *GetLastSetPrimitivesMs() const { return LastSetPrimitivesMs; }
     unsigned GetTileWidth() const { return Tile.w; }
     unsigned GetTileHeight() const { return Tile.h; }
     const BoundingVolumesHierarchy &GetBVH() const { return Tree; }
@@ -128,6 +130,7 @@ private:
     enum UserSphereFlags : uint32_t { EM_NONZERO = 1u << 0, SPECULAR = 1u << 1, FUZZY = 1u << 2 };
 
     bool IsOK = false;
+    double LastSetPrimitivesMs[4] = {0, 0, 0, 0};
     gpuart_hip_ctx *Backend = nullptr;
     BoundingVolumesHierarchy Tree;
     struct { unsigned width, height; } Viewport{0, 0};

@@ -222,6 +222,11 @@ def test_committed_bench_lines_keep_the_contract(rnd, name):
         assert abs(ls["frac"] - r["valu_issue"]["frac"] * r["valu_issue"]["lane_util"]) < 2e-3
         for name in BL.RATIO_QUANTITIES:
             assert (r if name == "" else r[name])["quantity"] == BL.RATIO_QUANTITIES[name]
+    if rnd >= "r06":  # what binds, named; the contract's fraction under both observed schedules
+        b = r["binding"]
+        assert b["resource"] in b["candidates"] and b["frac"] == max(v for v in b["candidates"].values() if v is not None) and 0 < b["frac"] < 1
+        pr = r["per_launch_frac_range"]
+        assert pr["min"] <= r["frac"] <= pr["max"] and pr["rocprof_trace_child"] is not None
     if rnd >= "r04":  # round 4's additions
         assert d["metric_version"] == (3 if rnd == "r04" else 4) and "value_definition" in d
         if rnd == "r04":

@@ -19,11 +19,14 @@ for _ in range(4):
 r = B.Renderer(64, 64, cam)
 r.set_primitives(prims)
 best = 1e9
+lib = None
 for _ in range(4):
     t = time.perf_counter(); r.set_primitives(prims); r.finish(); best = min(best, time.perf_counter() - t)
+    lib = min(lib or r.last_setprims_ms(), r.last_setprims_ms())
 be = r.backend
 t = time.perf_counter(); be.upload_bvh(q); be.finish(); up = time.perf_counter() - t
 print("%s: %d primitives, %d quads (%.1f MB), depth %d, threads %s: host build + compile %.1f ms; upload (validate, re-layout, copy) %.1f ms; "
-      "Renderer::SetPrimitives %.1f ms" % (which, len(descs), len(q), q.nbytes / 1e6, depth, os.environ.get("GPUART_BVH_THREADS", "default"),
-                                           best_host * 1e3, up * 1e3, best * 1e3))
+      "Renderer::SetPrimitives %.1f ms in the library (build %.1f + compile %.1f + re-layout and upload %.1f; %.1f ms with the harness that makes and deletes one "
+      "object per primitive)" % (which, len(descs), len(q), q.nbytes / 1e6, depth, os.environ.get("GPUART_BVH_THREADS", "default"),
+                                 best_host * 1e3, up * 1e3, lib[0], lib[1], lib[2], lib[3], best * 1e3))
 r.close()
