@@ -189,7 +189,8 @@ def _lines():
     for rnd, names in (("r03", ["bench.json", "bench_driver_config.json", "bench_dragon871k.json", "bench_cfg2.json", "bench_4k.json"]),
                        ("r04", sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r04", "bench*.json"))
                               if "steps1" not in p)),  # (bench_steps1.json: --no-profile --no-cpu-baseline, one pass alone: no roofline counters)
-                       ("r05", sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r05", "bench*.json")) if "steps1" not in p))):
+                       ("r05", sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r05", "bench*.json")) if "steps1" not in p)),
+                       ("r06", sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r06", "bench*.json")) if "steps1" not in p))):
         out += [(rnd, n) for n in names]
     return out
 
