@@ -47,6 +47,25 @@ def test_a_held_call_comes_back_within_its_bound():
     assert 0.03 < time.perf_counter() - t0 < 1.0
 
 
+def test_bounded_calls_of_several_threads_run_side_by_side():
+    """Round 6: every calling thread has its own helper. Six threads each hold a bounded call for 300 ms: together they take ~300 ms, not
+    1.8 s — the ranks of a one-thread-per-rank process are all inside ncclCommInitRank at once, each waiting for the others; behind ONE helper
+    and one lock (round 5) the first rank was let in and the peers it waited for were kept outside (tests/test_gather_inprocess.py found it)."""
+    import threading
+    from gpuart_amd import binding as B
+    L = B.hip_lib()
+    rcs = []
+    def call():
+        rcs.append(L.gpuart_hip_test_bounded_call(300, 5000, 0))
+    ts = [threading.Thread(target=call) for _ in range(6)]
+    t0 = time.perf_counter()
+    for t in ts: t.start()
+    for t in ts: t.join(30)
+    dt = time.perf_counter() - t0
+    assert rcs == [0] * 6 and 0.29 < dt < 1.2, (rcs, dt)
+    assert not B.comm_stuck()
+
+
 def test_after_a_call_that_never_returned_the_communicator_layer_refuses_at_once():
     p, dt = _child("""
 from gpuart_amd import binding as B
