@@ -25,9 +25,9 @@ CLI = os.path.join(ROOT, "gpuart_amd", "bin", "gpuart_cli")
 pytestmark = [pytest.mark.gpu, pytest.mark.rccl]
 
 
-def _child(code, stub, timeout=300):
+def _child(code, stub, timeout=300, **more):
     env = dict(os.environ, GPUART_HIP_RCCL_LIBRARY=stub, GPUART_HIP_TEST_SHARED_DEVICE="1", GPUART_HIP_COMM_TIMEOUT_MS="60000",
-               GPUART_HIP_GATHER_TIMEOUT_MS="60000", GPUART_HIP_PHASE_LOG="0")
+               GPUART_HIP_GATHER_TIMEOUT_MS="60000", GPUART_HIP_PHASE_LOG="0", **more)
     return subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % ROOT + code], capture_output=True, text=True, env=env,
                           timeout=timeout)
 
@@ -104,6 +104,31 @@ assert not B.comm_stuck()
 print("gathered", after[0] - before[0])
 """ % N, rccl_stub)
     assert p.returncode == 0 and "gathered" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_the_bench_shape_1080p_over_eight_ranks(rccl_stub):
+    """bench.py --gpus 8 as far as one GPU can run it: the 1920x1080 frame of Scene D's camera on the box scene, 8 shares of 17 / 16 bands (135
+    bands of 8 rows), two passes, gathered on rank 0 through the library's transfers — equal to the single-context frame bit for bit, 7
+    transfers of the peers' 135 or 128 rows each. (Two pass lanes and runs of at most 4 passes per context: nine contexts share one device.)"""
+    p = _child(_SETUP + """
+N, W, H, K = 8, 1920, 1080, 2
+one = renderer(W, H); render(one, K)
+want = one.read_radiance(True)
+ranks = [renderer(W, H, (k, N)) for k in range(N)]
+shares = [B.share_of_rank(W, H, k, N) for k in range(N)]
+assert [g.th for g in shares] == [136] * 7 + [128] and sum(g.th for g in shares) == H
+for r in ranks: render(r, K)
+bes = [r.backend for r in ranks]
+B.comm_init_all(bes)
+before = served()
+full = B.gather_all_read(bes, 1, float(K), 0, W, H)
+after = served()
+assert same(full, want), "%d pixels differ" % int((full.view(np.uint32) != want.view(np.uint32)).any(-1).sum())
+assert after[0] - before[0] == 7 and after[1] - before[1] == 16 * W * (H - 136), (before, after)
+for b in bes: b.comm_destroy()
+print("gathered 1080p")
+""", rccl_stub, GPUART_HIP_PASSES_IN_FLIGHT="2", GPUART_HIP_MAX_BATCH="4")
+    assert p.returncode == 0 and "gathered 1080p" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
 
 
 @pytest.mark.parametrize("N", [2, 3, 8])
