@@ -131,6 +131,37 @@ print("gathered 1080p")
     assert p.returncode == 0 and "gathered 1080p" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
 
 
+def test_random_frames_ranks_and_roots(rccl_stub):
+    """Twenty-four random decompositions in one process: N in 2..8 ranks, frames of 8..260 x 8..150 pixels (ragged widths, ragged last bands, more
+    ranks than bands -> empty shares, the root's own share empty), a random root, one or two passes; every gathered frame == the single-context
+    frame, bit for bit, and every non-empty peer sent exactly its rows."""
+    p = _child(_SETUP + """
+rng = np.random.RandomState(20261005)
+done = 0
+for case in range(24):
+    N = int(rng.randint(2, 9)); W = int(rng.randint(8, 261)); H = int(rng.choice([8, 9, 15, 16, 17, 40, 63, 64, 65, 100, 150])); K = int(rng.randint(1, 3))
+    root = int(rng.randint(N))
+    one = renderer(W, H); render(one, K)
+    want = one.read_radiance(True)
+    ranks = [renderer(W, H, (k, N)) for k in range(N)]
+    shares = [B.share_of_rank(W, H, k, N) for k in range(N)]
+    for r in ranks: render(r, K)
+    bes = [r.backend for r in ranks]
+    B.comm_init_all(bes)
+    before = served()
+    full = B.gather_all_read(bes, 1, float(K), root, W, H)
+    after = served()
+    assert same(full, want), "case %d (N %d, %dx%d, root %d): %d pixels differ" % (case, N, W, H, root, int((full.view(np.uint32) != want.view(np.uint32)).any(-1).sum()))
+    assert after[0] - before[0] == sum(1 for k, g in enumerate(shares) if k != root and g.th)
+    assert after[1] - before[1] == 16 * W * sum(g.th for k, g in enumerate(shares) if k != root)
+    for b in bes: b.comm_destroy()
+    for r in ranks + [one]: r.close()
+    done += 1
+print("random gathers", done)
+""", rccl_stub, timeout=600, GPUART_HIP_PASSES_IN_FLIGHT="2", GPUART_HIP_MAX_BATCH="2")
+    assert p.returncode == 0 and "random gathers 24" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+
+
 @pytest.mark.parametrize("N", [2, 3, 8])
 def test_one_thread_per_rank_gathers_the_same_frame(rccl_stub, N):
     """_comm_init + _gather: every rank on its own thread with its own context, the way bench.py's ranks and any one-process-per-GPU
