@@ -462,7 +462,7 @@ int gpuart_hip_create(int device, gpuart_hip_ctx **out) {
     c->lean_kernels = env_u32("GPUART_HIP_LEAN_KERNELS", 1, 0, 1) != 0;
     c->plan.min_run_paths = (size_t)env_u32("GPUART_HIP_MIN_RUN_KPATHS", 2048, 64, 65536) << 10;
     c->plan.lane_budget = (size_t)env_u32("GPUART_HIP_LANE_BUDGET_MB", 32768, 64, 262144) << 20;
-    c->plan.small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 6400, 0, 1 << 20) << 10;
+    c->plan.small_paths = (size_t)env_u32("GPUART_HIP_SMALL_KPATHS", 8500, 0, 1 << 20) << 10;
     c->gather_timeout_ms = env_u32("GPUART_HIP_GATHER_TIMEOUT_MS", 60000, 0, 3600000);
     for (auto &l : c->lanes) {
         if (hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking) != hipSuccess ||

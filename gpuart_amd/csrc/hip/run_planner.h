@@ -20,7 +20,7 @@ struct RunPlanner {
     uint32_t lanes_total = 8;                  ///< pass lanes that exist (GPUART_HIP_PASSES_IN_FLIGHT)
     size_t batch_paths = (size_t)16 << 20;     ///< passes are batched while one run stays within this many paths
     size_t min_run_paths = (size_t)2 << 20;    ///< a pipeline run is not made smaller than this many paths
-    size_t small_paths = (size_t)6400 << 10;   ///< mode 0: a planned sequence of at most this many paths is ONE k_run launch (0: never)
+    size_t small_paths = (size_t)8500 << 10;   ///< mode 0: a planned sequence of at most this many paths is ONE k_run launch (0: never)
     size_t lane_budget = (size_t)32 << 30;     ///< bytes of wavefront path state over all lanes (8 lanes of 8 passes at 1080p: 17.6 GB)
     double plan_run_factor = 0;                ///< 0: as many equal runs as lanes (plan()); > 0: the rule of rounds 2-4, run length = this x sqrt(planned work) in units of 2M paths
 
@@ -64,7 +64,8 @@ struct RunPlanner {
     /// Whether a run of `count` passes goes through the persistent run kernel (k_run) rather than the launch pipeline.
     /// Measured on cfg3 (profiles/r02/k_run_vs_pipeline.txt): one pass alone 2.2 vs 3.4 ms, two 1.65 vs 1.98, three 1.47 vs 1.56,
     /// four 1.36 vs 1.31, 64 1.19 vs 0.93 ms per pass — k_run has no chain of dependent launches, the pipeline packs lanes better
-    /// once several runs overlap. Mode 0 uses k_run when the whole planned sequence is small; small_paths = 0 turns that off.
+    /// once several runs overlap. Round 6 (k_run's loop control in scalar registers: -6 %): four passes 1.10 vs 1.16, five 1.07 vs 1.01
+    /// (profiles/r06/k_run_vs_pipeline_small_k.txt): the crossover moved from 3-4 to 4-5 passes of a 1080p frame, small_paths 6.4 M -> 8.5 M. Mode 0 uses k_run when the whole planned sequence is small; small_paths = 0 turns that off.
     bool uses_run_kernel(size_t count) const {
         if (mode == 1 || mode == 4 || mode == 5) return true;
         if (mode != 0 || !small_paths) return false;

@@ -10,7 +10,7 @@ import pytest
 from gpuart_amd import binding as B
 
 RESIZE, SHARE, PLAN, MODE, PASS, FLUSH, ALLOC_FAILS = range(7)
-DEFAULTS = dict(batch_limit=64, lanes=8, batch_mpaths=16, min_run_kpaths=2048, small_kpaths=6400, lane_budget_mb=16384, plan_percent=75)
+DEFAULTS = dict(batch_limit=64, lanes=8, batch_mpaths=16, min_run_kpaths=2048, small_kpaths=8500, lane_budget_mb=16384, plan_percent=75)
 
 
 def plan(ops, max_runs=4096, **cfg):
@@ -77,6 +77,11 @@ def test_planner_defaults_match_the_design_notes():
     assert r == [(2, 2073600, 8, 1, 1, 0)]
     r = plan([(RESIZE, 1920, 1080), (PLAN, 3, 0), (PASS, 3, 0)])
     assert [x[3:5] for x in r] == [(3, 1)]
+    # round 6: four passes of a 1080p frame are still one k_run launch, five go through the pipeline (profiles/r06/k_run_vs_pipeline_small_k.txt)
+    r = plan([(RESIZE, 1920, 1080), (PLAN, 4, 0), (PASS, 4, 0)], small_kpaths=0)     # 0 = the library's own default
+    assert [x[3:5] for x in r] == [(4, 1)]
+    r = plan([(RESIZE, 1920, 1080), (PLAN, 5, 0), (PASS, 5, 0), (FLUSH, 0, 0)], small_kpaths=0)
+    assert all(x[4] == 0 for x in r) and sum(x[3] for x in r) == 5
     r = plan([(RESIZE, 1920, 1080), (PLAN, 64, 0), (PASS, 64, 0), (FLUSH, 0, 0)])
     assert all(x[4] == 0 for x in r) and sum(x[3] for x in r) == 64 and max(x[3] for x in r) <= 8
     r = plan([(RESIZE, 3840, 2160), (PASS, 5, 0), (FLUSH, 0, 0)])
