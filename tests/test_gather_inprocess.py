@@ -131,6 +131,33 @@ print("gathered 1080p")
     assert p.returncode == 0 and "gathered 1080p" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
 
 
+def test_cfg5_decomposition_7680x4320_over_eight_ranks(rccl_stub):
+    """BASELINE.json's cfg5 as a decomposition: the 7680x4320 frame as eight interleaved shares of 68 / 67 bands (540 bands of 8 rows), gathered on
+    rank 0 through the library's transfers (seven of 66 MB each, 531 MB assembled) — equal to the frame one context renders, bit for bit. One
+    pass of the box scene: the 256 passes per pixel of the configuration are covered on a share by test_cfg4_and_cfg5_at_their_stated_depth,
+    the scaling by profiles/r06/tile_scaling_one_gpu_cfg5.txt; what remains for an 8-GPU node is RCCL itself."""
+    p = _child(_SETUP + """
+N, W, H, K = 8, 7680, 4320, 1
+one = renderer(W, H); render(one, K)
+want = one.read_radiance(True)
+one.close()
+ranks = [renderer(W, H, (k, N)) for k in range(N)]
+shares = [B.share_of_rank(W, H, k, N) for k in range(N)]
+assert [g.th for g in shares] == [544] * 4 + [536] * 4 and sum(g.th for g in shares) == H
+for r in ranks: render(r, K)
+bes = [r.backend for r in ranks]
+B.comm_init_all(bes)
+before = served()
+full = B.gather_all_read(bes, 1, float(K), 0, W, H)
+after = served()
+assert same(full, want), "%d pixels differ" % int((full.view(np.uint32) != want.view(np.uint32)).any(-1).sum())
+assert after[0] - before[0] == 7 and after[1] - before[1] == 16 * W * (H - 544), (before, after)
+for b in bes: b.comm_destroy()
+print("gathered 8K")
+""", rccl_stub, timeout=600, GPUART_HIP_PASSES_IN_FLIGHT="2", GPUART_HIP_MAX_BATCH="1")
+    assert p.returncode == 0 and "gathered 8K" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+
+
 def test_random_frames_ranks_and_roots(rccl_stub):
     """Twenty-four random decompositions in one process: N in 2..8 ranks, frames of 8..260 x 8..150 pixels (ragged widths, ragged last bands, more
     ranks than bands -> empty shares, the root's own share empty), a random root, one or two passes; every gathered frame == the single-context
